@@ -1,0 +1,1282 @@
+// api.hip - the C ABI of librbl.so (include/rbl.h): solver handle, data path, the ADMM
+// iteration of src/optim/algorithms.py:119-164 as a sequence of device phases, and the
+// kernel-level entry points used by the parity tests.  Host code only orchestrates:
+// every arithmetic step runs in a HIP kernel; there is no CPU fallback.
+#include "rbl_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <chrono>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------- error state
+static thread_local std::string g_err;
+
+void rbl_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+// -------------------------------------------------------------------------------- handle
+struct rbl_solver {
+    rbl_config cfg;
+    int64_t n = 0, d = 0, ld = 0, nt = 0, off = 0;
+    int storage = 0;
+    size_t esz = 4;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    int num_cu = 256;
+    bool data_ready = false, gram_ready = false, gram_local_done = false, v_valid = false;
+    bool sorted_path = false;  // weight function needs sort + PAV
+
+    void* D = nullptr;
+    double *w = nullptr, *w_prev = nullptr, *q = nullptr, *G = nullptr, *w_tmp = nullptr;
+    double *z = nullptr, *lam = nullptr, *v = nullptr, *m = nullptr, *c = nullptr;
+    double *sigma_a = nullptr, *sigma_b = nullptr;
+    double *slab = nullptr;
+    size_t slab_bytes = 0;
+    double *partials = nullptr, *red = nullptr, *red2 = nullptr;
+    signed char* ysign = nullptr;
+    double* colstats = nullptr;  // [sum(ld) | sumsq(ld) | mean(ld) | inv_std(ld)]
+
+    SortWorkspace sw{};
+    PavWorkspace pw{};
+    double *locx_a = nullptr, *chunk_a = nullptr, *cph_a = nullptr, *cpl_a = nullptr;
+    double *locx_b = nullptr, *chunk_b = nullptr, *cph_b = nullptr, *cpl_b = nullptr;
+    Prefix pa{}, pb{}, pm{};
+    WstepWorkspace ww{};
+    double L = 0.0;
+
+    // host-side state of the iteration (algorithms.py:32-52)
+    double rho = 0.0, smooth_t = 1.0, sigma0 = 0.0;
+    int64_t iter = 0;
+    // scratch of the step in flight
+    double step_rho = 0.0;
+    int inner_iters = 0;
+    int want_obj = 0;
+    bool obj_is_risk = false;
+
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};  // gemv begin/end, gemvt begin/end
+    bool profile = false, kev_pending[2] = {false, false};
+    double kt_ms[2] = {0.0, 0.0};
+    int64_t kt_n[2] = {0, 0};
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+    if (e != hipSuccess) {
+        rbl_set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return RBL_ERR_NOMEM;
+    }
+    return RBL_OK;
+}
+
+void dev_free(void* p) {
+    if (p) (void)hipFree(p);
+}
+
+int check_device(int* count_out) {
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0) {
+        (void)hipGetLastError();
+        rbl_set_error("no HIP device available (librbl has no CPU fallback)");
+        return RBL_ERR_NO_DEVICE;
+    }
+    if (count_out) *count_out = cnt;
+    return RBL_OK;
+}
+
+double default_rho(int wf) {
+    // src/optim/algorithms.py:47-52
+    if (wf == RBL_W_EHRM) return 1e-4;
+    if (wf == RBL_W_AORR || wf == RBL_W_AORR_DC) return 2e-7;
+    return 1e-5;
+}
+
+int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+int fill_const(double* p, int64_t count, double val, hipStream_t s) {
+    std::vector<double> h((size_t)(count < (1 << 20) ? count : (1 << 20)), val);
+    for (int64_t o = 0; o < count; o += (int64_t)h.size()) {
+        int64_t c = count - o < (int64_t)h.size() ? count - o : (int64_t)h.size();
+        RBL_HIP(hipMemcpyAsync(p + o, h.data(), sizeof(double) * c, hipMemcpyHostToDevice, s));
+        RBL_HIP(hipStreamSynchronize(s));
+    }
+    return RBL_OK;
+}
+
+int alloc_sort(SortWorkspace& sw, int64_t n, bool with_vals) {
+    RBL_TRY(dev_alloc(&sw.keys[0], (size_t)n));
+    RBL_TRY(dev_alloc(&sw.keys[1], (size_t)n));
+    if (with_vals) {
+        RBL_TRY(dev_alloc(&sw.vals[0], (size_t)n));
+        RBL_TRY(dev_alloc(&sw.vals[1], (size_t)n));
+    }
+    RBL_TRY(dev_alloc((unsigned char**)&sw.spine, sort_spine_bytes()));
+    RBL_TRY(dev_alloc(&sw.bin_total, 256));
+    RBL_TRY(dev_alloc(&sw.bin_base, 256));
+    return RBL_OK;
+}
+
+void free_sort(SortWorkspace& sw) {
+    dev_free(sw.keys[0]); dev_free(sw.keys[1]); dev_free(sw.vals[0]); dev_free(sw.vals[1]);
+    dev_free(sw.spine); dev_free(sw.bin_total); dev_free(sw.bin_base);
+    sw = SortWorkspace{};
+}
+
+int alloc_pav(PavWorkspace& pw, int64_t n) {
+    const int64_t nc = pav_num_chunks(n);
+    RBL_TRY(dev_alloc(&pw.ms, (size_t)n));
+    RBL_TRY(dev_alloc(&pw.u, (size_t)n));
+    RBL_TRY(dev_alloc(&pw.locx_m, (size_t)n + 1));
+    RBL_TRY(dev_alloc(&pw.chunk_m, (size_t)nc));
+    RBL_TRY(dev_alloc(&pw.cph_m, (size_t)nc));
+    RBL_TRY(dev_alloc(&pw.cpl_m, (size_t)nc));
+    RBL_TRY(dev_alloc(&pw.recs, (size_t)pav_num_recs(n)));
+    RBL_TRY(dev_alloc(&pw.counters, 4));
+    RBL_TRY(dev_alloc(&pw.partials, (size_t)reduce_blocks() * 4));
+    RBL_TRY(dev_alloc(&pw.branch, 1));
+    return RBL_OK;
+}
+
+void free_pav(PavWorkspace& pw) {
+    dev_free(pw.ms); dev_free(pw.u); dev_free(pw.locx_m); dev_free(pw.chunk_m); dev_free(pw.cph_m);
+    dev_free(pw.cpl_m); dev_free(pw.recs); dev_free(pw.counters); dev_free(pw.partials); dev_free(pw.branch);
+    pw = PavWorkspace{};
+}
+
+int alloc_prefix(double** locx, double** chunk, double** cph, double** cpl, int64_t n) {
+    const int64_t nc = pav_num_chunks(n);
+    RBL_TRY(dev_alloc(locx, (size_t)n + 1));
+    RBL_TRY(dev_alloc(chunk, (size_t)nc));
+    RBL_TRY(dev_alloc(cph, (size_t)nc));
+    RBL_TRY(dev_alloc(cpl, (size_t)nc));
+    return RBL_OK;
+}
+
+int alloc_wstep(WstepWorkspace& ww, int64_t ld) {
+    RBL_TRY(dev_alloc(&ww.yk, (size_t)ld));
+    RBL_TRY(dev_alloc(&ww.Gy, (size_t)ld));
+    RBL_TRY(dev_alloc(&ww.wn, (size_t)ld));
+    RBL_TRY(dev_alloc(&ww.r, (size_t)ld));
+    RBL_TRY(dev_alloc(&ww.p, (size_t)ld));
+    RBL_TRY(dev_alloc(&ww.scal, 8));
+    RBL_TRY(dev_alloc(&ww.flags, 4));
+    return RBL_OK;
+}
+
+void free_wstep(WstepWorkspace& ww) {
+    dev_free(ww.yk); dev_free(ww.Gy); dev_free(ww.wn); dev_free(ww.r); dev_free(ww.p); dev_free(ww.scal);
+    dev_free(ww.flags);
+    ww = WstepWorkspace{};
+}
+
+int validate(const rbl_config* c) {
+    if (!c) {
+        rbl_set_error("config is NULL");
+        return RBL_ERR_INVALID;
+    }
+    if (c->n < 0 || c->d <= 0 || c->n_total < c->n || c->row_offset < 0 || c->row_offset + c->n > c->n_total) {
+        rbl_set_error("bad shape: n=%lld d=%lld n_total=%lld row_offset=%lld", (long long)c->n, (long long)c->d,
+                      (long long)c->n_total, (long long)c->row_offset);
+        return RBL_ERR_INVALID;
+    }
+    if (c->n_total <= 0) {
+        rbl_set_error("empty problem");
+        return RBL_ERR_INVALID;
+    }
+    if (c->loss != RBL_LOSS_BCE && c->loss != RBL_LOSS_HINGE) {
+        rbl_set_error("Unrecognized loss! Options: ['binary_cross_entropy', 'multinomial_cross_entropy', 'hinge']");
+        return RBL_ERR_INVALID;
+    }
+    if (c->weight_function < RBL_W_ERM || c->weight_function > RBL_W_EHRM) {
+        rbl_set_error("Unrecognized framework! Options: ['erm','extremile','superquantile','esrm','aorr','aorr_dc','ehrm']");
+        return RBL_ERR_INVALID;
+    }
+    if (c->has_B && c->loss != RBL_LOSS_BCE) {
+        rbl_set_error("erhm only can be with the binary_cross_entropy.");  // objective.py:57-58
+        return RBL_ERR_INVALID;
+    }
+    if (c->has_B && c->weight_function != RBL_W_EHRM) {
+        rbl_set_error("Unrecognized weight_function! Options: ['ehrm']");  // algorithms.py:65-68
+        return RBL_ERR_INVALID;
+    }
+    if (c->weight_function == RBL_W_EHRM && !c->objective_only && (!c->has_B || c->loss != RBL_LOSS_BCE)) {
+        rbl_set_error("ehrm needs B and binary_cross_entropy");
+        return RBL_ERR_INVALID;
+    }
+    if (c->weight_function != RBL_W_ERM && c->weight_function != RBL_W_EHRM) {
+        const int need = (c->weight_function == RBL_W_AORR || c->weight_function == RBL_W_AORR_DC) ? 2 : 1;
+        if (c->n_weight_args < need) {
+            rbl_set_error("args for framework is None!");  // objective.py:171-172
+            return RBL_ERR_INVALID;
+        }
+    }
+    if (!c->objective_only) {
+        if (c->wstep != RBL_WSTEP_L1 && c->wstep != RBL_WSTEP_L2 && c->wstep != RBL_WSTEP_SMOOTH_L1) {
+            rbl_set_error("w_flag can only be 0, 1 or 2.");  // algorithms.py:206
+            return RBL_ERR_INVALID;
+        }
+        if (!(c->reg > 0.0)) {
+            rbl_set_error("l1_reg or l2_reg must be a positive number");
+            return RBL_ERR_INVALID;
+        }
+    }
+    if (c->storage != RBL_STORE_F32 && c->storage != RBL_STORE_F64) {
+        rbl_set_error("storage must be RBL_STORE_F32 or RBL_STORE_F64");
+        return RBL_ERR_INVALID;
+    }
+    if (c->n_total >= (1LL << 32)) {
+        rbl_set_error("n_total must be < 2^32");
+        return RBL_ERR_INVALID;
+    }
+    return RBL_OK;
+}
+
+int build_sigma_prefix(rbl_solver* h) {
+    // sigma is static: its prefix sums are built once (pav.hip uses them every iteration)
+    RBL_TRY(launch_prefix(h->sigma_a, h->nt, h->locx_a, h->chunk_a, h->cph_a, h->cpl_a, h->stream));
+    h->pa = Prefix{h->locx_a, h->cph_a, h->cpl_a};
+    h->pb = h->pa;
+    if (h->cfg.weight_function == RBL_W_EHRM) {
+        RBL_TRY(launch_prefix(h->sigma_b, h->nt, h->locx_b, h->chunk_b, h->cph_b, h->cpl_b, h->stream));
+        h->pb = Prefix{h->locx_b, h->cph_b, h->cpl_b};
+    }
+    h->pm = Prefix{h->pw.locx_m, h->pw.cph_m, h->pw.cpl_m};
+    return RBL_OK;
+}
+
+int ensure_v(rbl_solver* h) {
+    if (h->v_valid) return RBL_OK;
+    RBL_TRY(launch_gemv(h->storage, h->D, h->n, h->ld, h->w, h->v, h->num_cu, h->stream));
+    h->v_valid = true;
+    return RBL_OK;
+}
+
+// Sorted-path z-step over the n_total values in msrc (device), writing the local slice.
+int z_step_sorted(rbl_solver* h, const double* msrc, double rho) {
+    hipStream_t s = h->stream;
+    const int64_t nt = h->nt;
+    RBL_TRY(launch_keys_from_m(nt, msrc, h->sw.keys[0], h->sw.vals[0], s));
+    RBL_TRY(launch_radix_sort(h->sw, nt, true, s));
+    RBL_TRY(launch_unflip_keys(nt, h->sw.keys[0], h->pw.ms, s));
+    RBL_TRY(launch_prefix(h->pw.ms, nt, h->pw.locx_m, h->pw.chunk_m, h->pw.cph_m, h->pw.cpl_m, s));
+    const bool ehrm = h->cfg.weight_function == RBL_W_EHRM;
+    if (ehrm) {
+        RBL_TRY(launch_ehrm_branch(nt, h->sigma_a, h->sigma_b, h->cfg.B, rho, h->pw.ms, h->pw.partials, h->pw.branch,
+                                   -1, s));
+        RBL_TRY(launch_pav_init_ehrm(nt, h->sigma_a, h->sigma_b, rho, h->pw.ms, h->pw.u, h->pw.branch, s));
+    } else {
+        RBL_TRY(launch_pav_init(h->cfg.loss, nt, h->sigma_a, rho, h->pw.ms, h->pw.u, s));
+    }
+    RBL_TRY(launch_pav_tree(h->cfg.loss, nt, rho, h->pw.u, h->pa, h->pb, h->pm, ehrm ? h->pw.branch : nullptr,
+                            h->pw.recs, h->pw.counters, s));
+    RBL_TRY(launch_scatter_z(nt, h->pw.u, h->sw.vals[0], ehrm ? h->pw.branch : nullptr, h->cfg.B, ehrm ? 1 : 0, rho,
+                             h->lam, h->z, h->c, h->off, h->n, s));
+    return RBL_OK;
+}
+
+// sum_i sigma_i * loss_(i) from n_total values of v (device) -> *out_dev
+int risk_from_v(rbl_solver* h, const double* v_all, double* out_dev) {
+    hipStream_t s = h->stream;
+    if (h->cfg.weight_function == RBL_W_ERM)
+        return launch_loss_sum(h->cfg.loss, h->nt, v_all, 1.0 / (double)h->nt, h->partials, out_dev, s);
+    RBL_TRY(launch_loss_keys(h->nt, v_all, h->sw.keys[0], s));
+    RBL_TRY(launch_radix_sort(h->sw, h->nt, false, s));
+    return launch_sorted_loss_dot(h->cfg.loss, h->nt, h->sw.keys[0], h->sigma_a, h->partials, out_dev, s);
+}
+
+}  // namespace
+
+// ================================================================================ C ABI
+extern "C" {
+
+int rbl_version(void) { return RBL_VERSION; }
+
+const char* rbl_last_error(void) { return g_err.c_str(); }
+
+int rbl_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return cnt;
+}
+
+int rbl_destroy(rbl_solver* h) {
+    if (!h) return RBL_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    dev_free(h->D); dev_free(h->w); dev_free(h->w_prev); dev_free(h->q); dev_free(h->G); dev_free(h->w_tmp);
+    dev_free(h->z); dev_free(h->lam); dev_free(h->v); dev_free(h->m); dev_free(h->c);
+    dev_free(h->sigma_a); dev_free(h->sigma_b); dev_free(h->slab); dev_free(h->partials); dev_free(h->red);
+    dev_free(h->red2); dev_free(h->ysign); dev_free(h->colstats);
+    free_sort(h->sw);
+    free_pav(h->pw);
+    dev_free(h->locx_a); dev_free(h->chunk_a); dev_free(h->cph_a); dev_free(h->cpl_a);
+    dev_free(h->locx_b); dev_free(h->chunk_b); dev_free(h->cph_b); dev_free(h->cpl_b);
+    free_wstep(h->ww);
+    for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : h->kev) if (e) (void)hipEventDestroy(e);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return RBL_OK;
+}
+
+int rbl_create(const rbl_config* cfg, rbl_solver** out) {
+    if (!out) {
+        rbl_set_error("out is NULL");
+        return RBL_ERR_INVALID;
+    }
+    *out = nullptr;
+    RBL_TRY(validate(cfg));
+    int cnt = 0;
+    RBL_TRY(check_device(&cnt));
+    if (cfg->device < 0 || cfg->device >= cnt) {
+        rbl_set_error("device %d out of range (%d devices)", cfg->device, cnt);
+        return RBL_ERR_INVALID;
+    }
+    RBL_HIP(hipSetDevice(cfg->device));
+    rbl_solver* h = new rbl_solver();
+    h->cfg = *cfg;
+    h->n = cfg->n;
+    h->d = cfg->d;
+    h->ld = round_up(cfg->d, 4);
+    h->nt = cfg->n_total;
+    h->off = cfg->row_offset;
+    h->storage = cfg->storage;
+    h->esz = cfg->storage == RBL_STORE_F32 ? 4 : 8;
+    h->sorted_path = cfg->weight_function != RBL_W_ERM;
+    if (h->cfg.tol <= 0.0) h->cfg.tol = 1e-4;
+    if (h->cfg.w_tol <= 0.0) h->cfg.w_tol = 1e-13;
+    if (h->cfg.max_iter <= 0) h->cfg.max_iter = 200;
+    hipDeviceProp_t prop;
+    int rc = RBL_OK;
+#define CK(x)                        \
+    do {                             \
+        rc = (x);                    \
+        if (rc != RBL_OK) goto fail; \
+    } while (0)
+#define CKH(x)                                                                          \
+    do {                                                                                \
+        hipError_t e_ = (x);                                                            \
+        if (e_ != hipSuccess) {                                                         \
+            rbl_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            rc = RBL_ERR_HIP;                                                           \
+            goto fail;                                                                  \
+        }                                                                               \
+    } while (0)
+    CKH(hipGetDeviceProperties(&prop, cfg->device));
+    h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CKH(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    for (auto& e : h->ev) CKH(hipEventCreate(&e));
+    for (auto& e : h->kev) CKH(hipEventCreate(&e));
+    {
+        const int64_t n = h->n, ld = h->ld, nt = h->nt;
+        void* Dp = nullptr;
+        {
+            size_t bytes = (size_t)(n > 0 ? n : 1) * ld * h->esz;
+            hipError_t e = hipMalloc(&Dp, bytes);
+            if (e != hipSuccess) {
+                rbl_set_error("hipMalloc of the %lld x %lld matrix (%zu bytes) failed: %s", (long long)n,
+                              (long long)ld, bytes, hipGetErrorString(e));
+                rc = RBL_ERR_NOMEM;
+                goto fail;
+            }
+        }
+        h->D = Dp;
+        CK(dev_alloc(&h->w, (size_t)ld));
+        CK(dev_alloc(&h->w_tmp, (size_t)ld));
+        CK(dev_alloc(&h->v, (size_t)n));
+        CK(dev_alloc(&h->m, (size_t)n));
+        CK(dev_alloc(&h->sigma_a, (size_t)nt));
+        CK(dev_alloc(&h->sigma_b, (size_t)nt));
+        CK(dev_alloc(&h->partials, (size_t)reduce_blocks() * 4));
+        CK(dev_alloc(&h->red, 8));
+        CK(dev_alloc(&h->red2, 8));
+        CK(dev_alloc(&h->ysign, (size_t)n));
+        CK(dev_alloc(&h->colstats, (size_t)ld * 4));
+        h->slab_bytes = (size_t)gemvt_slab_rows(h->num_cu) * ld * sizeof(double) * 2;
+        if (!cfg->objective_only) {
+            size_t gb = gram_slab_bytes(ld, h->num_cu, n > 0 ? n : 1);
+            if (gb > h->slab_bytes) h->slab_bytes = gb;
+            CK(dev_alloc(&h->w_prev, (size_t)ld));
+            CK(dev_alloc(&h->q, (size_t)ld));
+            CK(dev_alloc(&h->G, (size_t)ld * ld));
+            CK(dev_alloc(&h->z, (size_t)n));
+            CK(dev_alloc(&h->lam, (size_t)n));
+            CK(dev_alloc(&h->c, (size_t)n));
+            CK(alloc_wstep(h->ww, ld));
+        }
+        CK(dev_alloc((unsigned char**)&h->slab, h->slab_bytes));
+        if (h->sorted_path) {
+            CK(alloc_sort(h->sw, nt, !cfg->objective_only));
+            if (!cfg->objective_only) {
+                CK(alloc_pav(h->pw, nt));
+                CK(alloc_prefix(&h->locx_a, &h->chunk_a, &h->cph_a, &h->cpl_a, nt));
+                if (cfg->weight_function == RBL_W_EHRM)
+                    CK(alloc_prefix(&h->locx_b, &h->chunk_b, &h->cph_b, &h->cpl_b, nt));
+            }
+        }
+        // sigma (objective.py:46-54): alphas, betas (= alphas unless ehrm)
+        CK(launch_weights(cfg->weight_function, nt, cfg->weight_args, h->sigma_a, h->sigma_b, h->stream));
+        h->sigma0 = 1.0 / (double)nt;
+        if (h->sorted_path && !cfg->objective_only) CK(build_sigma_prefix(h));
+        // initial state, algorithms.py:32-52 (n = num_row of the WHOLE problem)
+        CKH(hipMemsetAsync(h->w, 0, sizeof(double) * ld, h->stream));
+        CKH(hipMemsetAsync(h->w_tmp, 0, sizeof(double) * ld, h->stream));
+        if (!cfg->objective_only) {
+            const double reg = cfg->reg;
+            CK(fill_const(h->lam, n, 0.1 * reg / (double)nt, h->stream));
+            CK(fill_const(h->z, n, 0.1 * reg / (double)nt, h->stream));
+            CK(fill_const(h->w, h->d, 0.001 * reg / (double)h->d / (double)nt, h->stream));
+            CKH(hipMemsetAsync(h->q, 0, sizeof(double) * ld, h->stream));
+            h->rho = cfg->rho0 > 0.0 ? cfg->rho0 : default_rho(cfg->weight_function);
+            h->smooth_t = cfg->smooth_t > 0.0 ? cfg->smooth_t : 1.0;
+        }
+        CKH(hipStreamSynchronize(h->stream));
+    }
+#undef CK
+#undef CKH
+    *out = h;
+    return RBL_OK;
+fail:
+    rbl_destroy(h);
+    return rc;
+}
+
+#define RBL_ENTER(h)                                   \
+    do {                                               \
+        if (!(h)) {                                    \
+            rbl_set_error("solver handle is NULL");    \
+            return RBL_ERR_INVALID;                    \
+        }                                              \
+        RBL_HIP(hipSetDevice((h)->cfg.device));        \
+    } while (0)
+
+int rbl_set_stream(rbl_solver* h, void* hip_stream) {
+    RBL_ENTER(h);
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return RBL_OK;
+}
+
+int rbl_set_data(rbl_solver* h, const double* X, const double* y, int64_t ldx) {
+    RBL_ENTER(h);
+    if (!X || !y || ldx < h->d) {
+        rbl_set_error("set_data: bad arguments (ldx=%lld, d=%lld)", (long long)ldx, (long long)h->d);
+        return RBL_ERR_INVALID;
+    }
+    for (int64_t i = 0; i < h->n; ++i) {
+        if (!(y[i] == 1.0 || y[i] == -1.0)) {
+            rbl_set_error("set_data: labels must be +1/-1 (y[%lld] = %g)", (long long)i, y[i]);
+            return RBL_ERR_INVALID;
+        }
+    }
+    const int64_t n = h->n, d = h->d;
+    if (n > 0) {
+        int64_t chunk = (int64_t)((64LL << 20) / (sizeof(double) * (size_t)ldx));
+        if (chunk < 1) chunk = 1;
+        if (chunk > n) chunk = n;
+        double *Xd = nullptr, *yd = nullptr;
+        RBL_TRY(dev_alloc(&Xd, (size_t)chunk * ldx));
+        if (dev_alloc(&yd, (size_t)chunk) != RBL_OK) {
+            dev_free(Xd);
+            return RBL_ERR_NOMEM;
+        }
+        int rc = RBL_OK;
+        for (int64_t r0 = 0; r0 < n && rc == RBL_OK; r0 += chunk) {
+            const int64_t rows = n - r0 < chunk ? n - r0 : chunk;
+            hipError_t e = hipMemcpyAsync(Xd, X + r0 * ldx, sizeof(double) * rows * ldx, hipMemcpyHostToDevice, h->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(yd, y + r0, sizeof(double) * rows, hipMemcpyHostToDevice, h->stream);
+            if (e != hipSuccess) {
+                rbl_set_error("set_data: upload failed: %s", hipGetErrorString(e));
+                rc = RBL_ERR_HIP;
+                break;
+            }
+            rc = launch_form_D(h->storage, h->D, h->ld, r0, Xd, ldx, yd, rows, d, h->stream);
+            if (rc == RBL_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = RBL_ERR_HIP;
+        }
+        dev_free(Xd);
+        dev_free(yd);
+        RBL_TRY(rc);
+    }
+    h->data_ready = true;
+    h->gram_ready = h->gram_local_done = false;
+    h->v_valid = false;
+    return RBL_OK;
+}
+
+int rbl_synth_local(rbl_solver* h, uint64_t seed, double class_sep, double flip_y) {
+    RBL_ENTER(h);
+    // positions of the 2 informative + 2 redundant columns and the 2x2 mixing matrix:
+    // a small host-side LCG keyed by the seed (identical on every rank)
+    uint64_t st = seed * 6364136223846793005ull + 1442695040888963407ull;
+    auto next = [&]() {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        return (uint32_t)(st >> 33);
+    };
+    int special[4] = {-1, -1, -1, -1};
+    const int nspec = h->d >= 4 ? 4 : (int)h->d;
+    for (int k = 0; k < nspec; ++k) {
+        for (;;) {
+            int c = (int)(next() % (uint32_t)h->d);
+            bool dup = false;
+            for (int j = 0; j < k; ++j) dup |= special[j] == c;
+            if (!dup) {
+                special[k] = c;
+                break;
+            }
+        }
+    }
+    double mix[4];
+    for (int k = 0; k < 4; ++k) mix[k] = 2.0 * ((double)next() / 2147483648.0) - 1.0;
+    RBL_TRY(launch_synth(h->storage, h->D, h->n, h->ld, h->d, h->off, seed, class_sep, flip_y, special, mix, h->ysign,
+                         h->stream));
+    // column sums / sums of squares of the local rows -> colstats[0 .. 2 ld)
+    RBL_TRY(launch_colstats(h->storage, h->D, h->n, h->ld, h->slab, h->colstats, h->colstats + h->ld, h->num_cu,
+                            h->stream));
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    return RBL_OK;
+}
+
+int rbl_synth_finish(rbl_solver* h) {
+    RBL_ENTER(h);
+    // preprocessing.scale (load_data.py:115): (x - mean) / std with the population std
+    const int64_t ld = h->ld;
+    std::vector<double> st((size_t)ld * 4, 0.0);
+    RBL_HIP(hipMemcpy(st.data(), h->colstats, sizeof(double) * ld * 2, hipMemcpyDeviceToHost));
+    const double nt = (double)h->nt;
+    for (int64_t j = 0; j < ld; ++j) {
+        const double mean = st[j] / nt;
+        double var = st[ld + j] / nt - mean * mean;
+        if (!(var > 0.0)) var = 1.0;
+        st[2 * ld + j] = mean;
+        st[3 * ld + j] = 1.0 / std::sqrt(var);
+    }
+    RBL_HIP(hipMemcpy(h->colstats + 2 * ld, st.data() + 2 * ld, sizeof(double) * ld * 2, hipMemcpyHostToDevice));
+    RBL_TRY(launch_standardize_negy(h->storage, h->D, h->n, ld, h->d, h->colstats + 2 * ld, h->colstats + 3 * ld,
+                                    h->ysign, h->stream));
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    h->data_ready = true;
+    h->gram_ready = h->gram_local_done = false;
+    h->v_valid = false;
+    return RBL_OK;
+}
+
+int rbl_generate_synthetic(rbl_solver* h, uint64_t seed, double class_sep, double flip_y) {
+    RBL_ENTER(h);
+    if (h->nt != h->n) {
+        rbl_set_error("generate_synthetic: sharded problem - use rbl_synth_local, sum RBL_BUF_COLSTATS, rbl_synth_finish");
+        return RBL_ERR_STATE;
+    }
+    RBL_TRY(rbl_synth_local(h, seed, class_sep, flip_y));
+    return rbl_synth_finish(h);
+}
+
+int rbl_get_labels(rbl_solver* h, double* y_out) {
+    RBL_ENTER(h);
+    std::vector<signed char> t((size_t)h->n);
+    RBL_HIP(hipMemcpy(t.data(), h->ysign, (size_t)h->n, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < h->n; ++i) y_out[i] = (double)t[i];
+    return RBL_OK;
+}
+
+int rbl_gram_local(rbl_solver* h) {
+    RBL_ENTER(h);
+    if (!h->data_ready || h->cfg.objective_only) {
+        rbl_set_error("gram: no data (or objective-only handle)");
+        return RBL_ERR_STATE;
+    }
+    RBL_TRY(launch_gram(h->storage, h->D, h->n, h->ld, h->d, h->slab, h->G, h->num_cu, h->stream));
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    h->gram_local_done = true;
+    return RBL_OK;
+}
+
+int rbl_gram_finish(rbl_solver* h) {
+    RBL_ENTER(h);
+    if (!h->gram_local_done) {
+        rbl_set_error("gram_finish before gram_local");
+        return RBL_ERR_STATE;
+    }
+    double lam = 0.0;
+    RBL_TRY(launch_power_iteration(h->G, h->ld, h->ww.yk, h->ww.Gy, h->ww.scal, 100, &lam, h->stream));
+    h->L = 1.02 * lam;
+    if (!(h->L > 0.0)) h->L = 1.0;
+    h->gram_ready = true;
+    return RBL_OK;
+}
+
+int rbl_get_D(rbl_solver* h, double* out) {
+    RBL_ENTER(h);
+    if (!h->data_ready) {
+        rbl_set_error("get_D: no data");
+        return RBL_ERR_STATE;
+    }
+    const int64_t n = h->n, d = h->d;
+    int64_t chunk = (64LL << 20) / (8 * d);
+    if (chunk < 1) chunk = 1;
+    double* tmp = nullptr;
+    RBL_TRY(dev_alloc(&tmp, (size_t)chunk * d));
+    int rc = RBL_OK;
+    for (int64_t r0 = 0; r0 < n && rc == RBL_OK; r0 += chunk) {
+        const int64_t rows = n - r0 < chunk ? n - r0 : chunk;
+        rc = launch_D_to_f64(h->storage, (const char*)h->D + (size_t)r0 * h->ld * h->esz, h->ld, rows, d, tmp, h->stream);
+        if (rc == RBL_OK &&
+            hipMemcpyAsync(out + r0 * d, tmp, sizeof(double) * rows * d, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+            rc = RBL_ERR_HIP;
+        if (rc == RBL_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = RBL_ERR_HIP;
+    }
+    dev_free(tmp);
+    return rc;
+}
+
+int rbl_get_state(rbl_solver* h, double* w, double* z, double* lam, double* rho, int64_t* iter, double* smooth_t) {
+    RBL_ENTER(h);
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    if (w) RBL_HIP(hipMemcpy(w, h->w, sizeof(double) * h->d, hipMemcpyDeviceToHost));
+    if (z && h->z) RBL_HIP(hipMemcpy(z, h->z, sizeof(double) * h->n, hipMemcpyDeviceToHost));
+    if (lam && h->lam) RBL_HIP(hipMemcpy(lam, h->lam, sizeof(double) * h->n, hipMemcpyDeviceToHost));
+    if (rho) *rho = h->rho;
+    if (iter) *iter = h->iter;
+    if (smooth_t) *smooth_t = h->smooth_t;
+    return RBL_OK;
+}
+
+int rbl_set_state(rbl_solver* h, const double* w, const double* z, const double* lam, const double* rho,
+                  const int64_t* iter, const double* smooth_t) {
+    RBL_ENTER(h);
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    if (w) {
+        RBL_HIP(hipMemcpy(h->w, w, sizeof(double) * h->d, hipMemcpyHostToDevice));
+        h->v_valid = false;
+    }
+    if (z && h->z) RBL_HIP(hipMemcpy(h->z, z, sizeof(double) * h->n, hipMemcpyHostToDevice));
+    if (lam && h->lam) RBL_HIP(hipMemcpy(h->lam, lam, sizeof(double) * h->n, hipMemcpyHostToDevice));
+    if (rho) h->rho = *rho;
+    if (iter) h->iter = *iter;
+    if (smooth_t) h->smooth_t = *smooth_t;
+    return RBL_OK;
+}
+
+int rbl_get_sigma(rbl_solver* h, double* alphas, double* betas) {
+    RBL_ENTER(h);
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    if (alphas) RBL_HIP(hipMemcpy(alphas, h->sigma_a, sizeof(double) * h->nt, hipMemcpyDeviceToHost));
+    if (betas) RBL_HIP(hipMemcpy(betas, h->sigma_b, sizeof(double) * h->nt, hipMemcpyDeviceToHost));
+    return RBL_OK;
+}
+
+// ------------------------------------------------------------------------------- phases
+static int require_ready(rbl_solver* h) {
+    if (h->cfg.objective_only) {
+        rbl_set_error("objective-only handle cannot step");
+        return RBL_ERR_STATE;
+    }
+    if (!h->data_ready) {
+        rbl_set_error("step before set_data / generate_synthetic");
+        return RBL_ERR_STATE;
+    }
+    if (!h->gram_ready) {
+        if (h->nt != h->n) {
+            rbl_set_error("sharded problem: call rbl_gram_local, sum RBL_BUF_G over ranks, rbl_gram_finish first");
+            return RBL_ERR_STATE;
+        }
+        RBL_TRY(rbl_gram_local(h));
+        RBL_TRY(rbl_gram_finish(h));
+    }
+    return RBL_OK;
+}
+
+int rbl_phase_m(rbl_solver* h) {
+    RBL_ENTER(h);
+    RBL_TRY(require_ready(h));
+    h->step_rho = h->rho;
+    RBL_HIP(hipEventRecord(h->ev[0], h->stream));
+    RBL_TRY(ensure_v(h));
+    if (h->sorted_path) RBL_TRY(launch_make_m(h->n, h->step_rho, h->v, h->lam, h->m, h->stream));
+    return RBL_OK;
+}
+
+int rbl_phase_z(rbl_solver* h, const void* m_all_dev) {
+    RBL_ENTER(h);
+    const double rho = h->step_rho;
+    if (!h->sorted_path) {
+        RBL_TRY(launch_erm_zc(h->cfg.loss, h->n, h->sigma0, rho, h->v, h->lam, h->m, h->z, h->c, h->stream));
+    } else {
+        const double* msrc = (const double*)m_all_dev;
+        if (!msrc) {
+            if (h->nt != h->n) {
+                rbl_set_error("phase_z: sharded rank-weighted problem needs the gathered m vector");
+                return RBL_ERR_STATE;
+            }
+            msrc = h->m;
+        }
+        RBL_TRY(z_step_sorted(h, msrc, rho));
+    }
+    RBL_HIP(hipEventRecord(h->ev[1], h->stream));
+    return RBL_OK;
+}
+
+int rbl_phase_q(rbl_solver* h) {
+    RBL_ENTER(h);
+    if (h->profile) RBL_HIP(hipEventRecord(h->kev[2], h->stream));
+    RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream));
+    if (h->profile) {
+        RBL_HIP(hipEventRecord(h->kev[3], h->stream));
+        h->kev_pending[1] = true;
+    }
+    RBL_HIP(hipEventRecord(h->ev[2], h->stream));
+    return RBL_OK;
+}
+
+int rbl_phase_w(rbl_solver* h) {
+    RBL_ENTER(h);
+    RBL_HIP(hipMemcpyAsync(h->w_prev, h->w, sizeof(double) * h->ld, hipMemcpyDeviceToDevice, h->stream));
+    int wstep = h->cfg.wstep;
+    RBL_TRY(run_wstep(wstep, h->G, h->ld, h->q, h->step_rho, h->cfg.reg, h->smooth_t, h->L, h->cfg.w_tol, 100000, h->w,
+                      h->ww, &h->inner_iters, h->stream));
+    RBL_TRY(launch_diffnorm2(h->ld, h->w, h->w_prev, h->red2, h->stream));
+    RBL_TRY(launch_reg_terms(h->ld, h->w, h->red2 + 1, h->stream));
+    RBL_HIP(hipEventRecord(h->ev[3], h->stream));
+    return RBL_OK;
+}
+
+int rbl_phase_dual(rbl_solver* h, int want_objective) {
+    RBL_ENTER(h);
+    if (h->profile) RBL_HIP(hipEventRecord(h->kev[0], h->stream));
+    RBL_TRY(launch_gemv(h->storage, h->D, h->n, h->ld, h->w, h->v, h->num_cu, h->stream));
+    if (h->profile) {
+        RBL_HIP(hipEventRecord(h->kev[1], h->stream));
+        h->kev_pending[0] = true;
+    }
+    h->v_valid = true;
+    RBL_HIP(hipEventRecord(h->ev[4], h->stream));
+    RBL_TRY(launch_dual(h->cfg.loss, h->n, h->step_rho, h->z, h->v, h->lam, h->partials, h->red, h->stream));
+    h->want_obj = want_objective;
+    h->obj_is_risk = false;
+    if (want_objective && h->sorted_path && h->nt == h->n) {
+        RBL_TRY(risk_from_v(h, h->v, h->red + 1));
+        h->obj_is_risk = true;
+    }
+    return RBL_OK;
+}
+
+int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
+    RBL_ENTER(h);
+    RBL_HIP(hipEventRecord(h->ev[5], h->stream));
+    double r[2], r2[3];
+    RBL_HIP(hipMemcpyAsync(r, h->red, sizeof(double) * 2, hipMemcpyDeviceToHost, h->stream));
+    RBL_HIP(hipMemcpyAsync(r2, h->red2, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
+    int br = -1;
+    unsigned merges = 0;
+    if (h->sorted_path) {
+        if (h->cfg.weight_function == RBL_W_EHRM)
+            RBL_HIP(hipMemcpyAsync(&br, h->pw.branch, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        RBL_HIP(hipMemcpyAsync(&merges, h->pw.counters, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    }
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    const double primal = std::sqrt(r[0] > 0.0 ? r[0] : 0.0);   // algorithms.py:135
+    const double dual = std::sqrt(r2[0] > 0.0 ? r2[0] : 0.0);   // algorithms.py:136
+    double objective = NAN;
+    if (h->want_obj) {
+        double risk = NAN;
+        if (h->obj_is_risk) risk = r[1];
+        else if (!h->sorted_path) risk = r[1] / (double)h->nt;  // erm: sum over ALL ranks of loss / n
+        objective = risk;
+        if (h->cfg.wstep == RBL_WSTEP_L2) objective += 0.5 * h->cfg.reg * r2[1];   // objective.py:83-84
+        else objective += 0.5 * h->cfg.reg * r2[2];                                 // objective.py:85-86
+    }
+    const bool conv = primal < h->cfg.tol && dual < h->cfg.tol;  // algorithms.py:137
+    const int64_t i = h->iter;
+    double rho_next = h->rho;
+    if (!conv) {
+        // algorithms.py:154-157: the only live branch of the schedule
+        const double cap = 217.0 * (double)h->d;
+        rho_next = h->rho * (primal > 1e-2 ? 1.02 : 1.07);
+        if (rho_next > cap) rho_next = cap;
+        if (h->cfg.wstep == RBL_WSTEP_SMOOTH_L1 && i >= 17) {
+            // algorithms.py:254-255 (python float %, both operands positive)
+            double t = h->smooth_t * 0.9;
+            if (t < 1e-9) t = 1e-9;
+            h->smooth_t = std::fmod(t, std::pow(rho_next, -0.1)) * std::pow((double)i, -0.1);
+        }
+    }
+    float ms[5] = {0, 0, 0, 0, 0};
+    (void)hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]);
+    (void)hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]);
+    (void)hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]);
+    (void)hipEventElapsedTime(&ms[3], h->ev[3], h->ev[4]);
+    (void)hipEventElapsedTime(&ms[4], h->ev[0], h->ev[5]);
+    for (int k = 0; k < 2; ++k) {
+        if (h->kev_pending[k]) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, h->kev[2 * k], h->kev[2 * k + 1]) == hipSuccess) {
+                h->kt_ms[k] += t;
+                h->kt_n[k] += 1;
+            }
+            h->kev_pending[k] = false;
+        }
+    }
+    (void)hipGetLastError();
+    if (out) {
+        out->iter = i + 1;
+        out->primal = primal;
+        out->dual = dual;
+        out->rho = h->rho;
+        out->rho_next = rho_next;
+        out->objective = objective;
+        out->converged = conv ? 1 : 0;
+        out->inner_iters = h->inner_iters;
+        out->ehrm_branch = br;
+        out->pav_merges = h->sorted_path ? (int)merges : -1;
+        out->ms_z = ms[0];
+        out->ms_q = ms[1];
+        out->ms_w = ms[2];
+        out->ms_v = ms[3];
+        out->ms_total = ms[4];
+    }
+    h->rho = rho_next;
+    h->iter = i + 1;
+    return RBL_OK;
+}
+
+int rbl_step(rbl_solver* h, int want_objective, rbl_stats* out) {
+    RBL_ENTER(h);
+    if (h->nt != h->n) {
+        rbl_set_error("rbl_step: sharded problem - drive the phase API with collectives in between");
+        return RBL_ERR_STATE;
+    }
+    RBL_TRY(rbl_phase_m(h));
+    RBL_TRY(rbl_phase_z(h, nullptr));
+    RBL_TRY(rbl_phase_q(h));
+    RBL_TRY(rbl_phase_w(h));
+    RBL_TRY(rbl_phase_dual(h, want_objective));
+    return rbl_phase_finish(h, out);
+}
+
+int rbl_solve(rbl_solver* h, int max_iter, int want_objective, rbl_stats* last, double* hist_objective,
+              double* hist_primal, double* hist_dual, double* hist_rho, double* hist_time_s, int64_t cap) {
+    RBL_ENTER(h);
+    if (max_iter <= 0) max_iter = h->cfg.max_iter;
+    rbl_stats st;
+    std::memset(&st, 0, sizeof(st));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0; it < max_iter; ++it) {
+        RBL_TRY(rbl_step(h, want_objective, &st));
+        const int64_t k = st.iter - 1;
+        if (k >= 0 && k < cap) {
+            if (hist_objective) hist_objective[k] = st.objective;
+            if (hist_primal) hist_primal[k] = st.primal;
+            if (hist_dual) hist_dual[k] = st.dual;
+            if (hist_rho) hist_rho[k] = st.rho;
+            if (hist_time_s)
+                hist_time_s[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+        if (st.converged) break;
+    }
+    if (last) *last = st;
+    return RBL_OK;
+}
+
+int rbl_finalize_smooth(rbl_solver* h) {
+    RBL_ENTER(h);
+    if (h->cfg.wstep != RBL_WSTEP_SMOOTH_L1) return RBL_OK;
+    RBL_TRY(launch_soft_threshold(h->ld, h->w, h->smooth_t, h->stream));
+    h->v_valid = false;
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    return RBL_OK;
+}
+
+int rbl_objective(rbl_solver* h, const double* w, int include_reg, double* out) {
+    RBL_ENTER(h);
+    if (!h->data_ready || !w || !out) {
+        rbl_set_error("objective: no data or NULL argument");
+        return RBL_ERR_STATE;
+    }
+    if (h->nt != h->n) {
+        rbl_set_error("objective: sharded handle - use the phase API");
+        return RBL_ERR_STATE;
+    }
+    RBL_HIP(hipMemcpyAsync(h->w_tmp, w, sizeof(double) * h->d, hipMemcpyHostToDevice, h->stream));
+    RBL_TRY(launch_gemv(h->storage, h->D, h->n, h->ld, h->w_tmp, h->m, h->num_cu, h->stream));
+    RBL_TRY(risk_from_v(h, h->m, h->red2 + 4));
+    RBL_TRY(launch_reg_terms(h->ld, h->w_tmp, h->red2 + 5, h->stream));
+    double r[3];
+    RBL_HIP(hipMemcpyAsync(r, h->red2 + 4, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    double val = r[0];
+    if (include_reg && h->cfg.reg > 0.0) {
+        if (h->cfg.wstep == RBL_WSTEP_L2) val += 0.5 * h->cfg.reg * r[1];
+        else val += 0.5 * h->cfg.reg * r[2];
+    }
+    *out = val;
+    return RBL_OK;
+}
+
+int rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles) {
+    RBL_ENTER(h);
+    void* p = nullptr;
+    int64_t cnt = 0;
+    switch (which) {
+        case RBL_BUF_M: p = h->m; cnt = h->n; break;
+        case RBL_BUF_Q: p = h->q; cnt = h->ld; break;
+        case RBL_BUF_RED: p = h->red; cnt = 2; break;
+        case RBL_BUF_G: p = h->G; cnt = h->ld * h->ld; break;
+        case RBL_BUF_V: p = h->v; cnt = h->n; break;
+        case RBL_BUF_Z: p = h->z; cnt = h->n; break;
+        case RBL_BUF_LAM: p = h->lam; cnt = h->n; break;
+        case RBL_BUF_W: p = h->w; cnt = h->ld; break;
+        case 8: p = h->colstats; cnt = 2 * h->ld; break;  // RBL_BUF_COLSTATS
+        default: rbl_set_error("unknown buffer id %d", which); return RBL_ERR_INVALID;
+    }
+    if (dev_ptr) *dev_ptr = p;
+    if (n_doubles) *n_doubles = cnt;
+    return RBL_OK;
+}
+
+// risk (sum sigma_i loss_(i)) of n_total values of v on the device -> host double
+int rbl_risk_from_v(rbl_solver* h, const void* v_all_dev, double* out) {
+    RBL_ENTER(h);
+    RBL_TRY(risk_from_v(h, (const double*)v_all_dev, h->red2 + 4));
+    RBL_HIP(hipMemcpyAsync(out, h->red2 + 4, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    return RBL_OK;
+}
+
+int rbl_kernel_time(rbl_solver* h, int which, double* total_ms, int64_t* launches) {
+    RBL_ENTER(h);
+    if (which < 0 || which > 1) return RBL_ERR_INVALID;
+    if (total_ms) *total_ms = h->kt_ms[which];
+    if (launches) *launches = h->kt_n[which];
+    return RBL_OK;
+}
+
+int rbl_reset_kernel_times(rbl_solver* h) {
+    RBL_ENTER(h);
+    h->kt_ms[0] = h->kt_ms[1] = 0.0;
+    h->kt_n[0] = h->kt_n[1] = 0;
+    return RBL_OK;
+}
+
+int rbl_profile_kernels(rbl_solver* h, int enable) {
+    RBL_ENTER(h);
+    h->profile = enable != 0;
+    return RBL_OK;
+}
+
+int rbl_info(rbl_solver* h, int64_t* ld, int* num_cu, double* lipschitz) {
+    RBL_ENTER(h);
+    if (ld) *ld = h->ld;
+    if (num_cu) *num_cu = h->num_cu;
+    if (lipschitz) *lipschitz = h->L;
+    return RBL_OK;
+}
+
+}  // extern "C"
+
+// =================================================== kernel-level entry points (host buffers)
+namespace {
+struct Scratch {
+    std::vector<void*> ptrs;
+    hipStream_t s = nullptr;
+    ~Scratch() {
+        for (void* p : ptrs) dev_free(p);
+        if (s) (void)hipStreamDestroy(s);
+    }
+    template <typename T>
+    T* alloc(size_t count) {
+        T* p = nullptr;
+        if (dev_alloc(&p, count) != RBL_OK) return nullptr;
+        ptrs.push_back(p);
+        return p;
+    }
+    template <typename T>
+    T* upload(const T* host, size_t count) {
+        T* p = alloc<T>(count);
+        if (p && count && hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return p;
+    }
+};
+
+int scratch_begin(Scratch& sc, int* num_cu) {
+    RBL_TRY(check_device(nullptr));
+    RBL_HIP(hipStreamCreateWithFlags(&sc.s, hipStreamNonBlocking));
+    if (num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        RBL_HIP(hipGetDevice(&dev));
+        RBL_HIP(hipGetDeviceProperties(&prop, dev));
+        *num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return RBL_OK;
+}
+
+#define SC_CHECK(p)                                          \
+    do {                                                     \
+        if (!(p)) {                                          \
+            rbl_set_error("scratch allocation/upload failed"); \
+            return RBL_ERR_NOMEM;                            \
+        }                                                    \
+    } while (0)
+
+// D (host fp64 n x d) -> device storage with ld padding
+int upload_matrix(Scratch& sc, int storage, int64_t n, int64_t d, const double* D, void** Dd, int64_t* ld_out) {
+    const int64_t ld = round_up(d, 4);
+    const size_t esz = storage == RBL_STORE_F32 ? 4 : 8;
+    std::vector<unsigned char> host((size_t)n * ld * esz, 0);
+    for (int64_t r = 0; r < n; ++r)
+        for (int64_t j = 0; j < d; ++j) {
+            if (storage == RBL_STORE_F32) ((float*)host.data())[r * ld + j] = (float)D[r * d + j];
+            else ((double*)host.data())[r * ld + j] = D[r * d + j];
+        }
+    unsigned char* p = sc.upload<unsigned char>(host.data(), host.size());
+    SC_CHECK(p);
+    *Dd = p;
+    *ld_out = ld;
+    return RBL_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rbl_k_prox(int loss, int64_t n, const double* sigma, double rho, const double* m, double* out) {
+    Scratch sc;
+    RBL_TRY(scratch_begin(sc, nullptr));
+    if (n <= 0) return RBL_OK;
+    double* ds = sc.upload(sigma, (size_t)n);
+    double* dm = sc.upload(m, (size_t)n);
+    double* dout = sc.alloc<double>((size_t)n);
+    SC_CHECK(ds && dm && dout);
+    RBL_TRY(launch_prox(loss, n, ds, rho, dm, dout, sc.s));
+    RBL_HIP(hipMemcpyAsync(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost, sc.s));
+    RBL_HIP(hipStreamSynchronize(sc.s));
+    return RBL_OK;
+}
+
+int rbl_k_sort(int64_t n, const double* keys, double* sorted_keys, uint32_t* perm) {
+    Scratch sc;
+    RBL_TRY(scratch_begin(sc, nullptr));
+    if (n <= 0) return RBL_OK;
+    double* dk = sc.upload(keys, (size_t)n);
+    SC_CHECK(dk);
+    SortWorkspace sw{};
+    sw.keys[0] = sc.alloc<u64>((size_t)n);
+    sw.keys[1] = sc.alloc<u64>((size_t)n);
+    sw.vals[0] = sc.alloc<u32>((size_t)n);
+    sw.vals[1] = sc.alloc<u32>((size_t)n);
+    sw.spine = (u32*)sc.alloc<unsigned char>(sort_spine_bytes());
+    sw.bin_total = sc.alloc<u32>(256);
+    sw.bin_base = sc.alloc<u32>(256);
+    double* ms = sc.alloc<double>((size_t)n);
+    SC_CHECK(sw.keys[0] && sw.keys[1] && sw.vals[0] && sw.vals[1] && sw.spine && sw.bin_total && sw.bin_base && ms);
+    RBL_TRY(launch_keys_from_m(n, dk, sw.keys[0], sw.vals[0], sc.s));
+    RBL_TRY(launch_radix_sort(sw, n, true, sc.s));
+    RBL_TRY(launch_unflip_keys(n, sw.keys[0], ms, sc.s));
+    if (sorted_keys) RBL_HIP(hipMemcpyAsync(sorted_keys, ms, sizeof(double) * n, hipMemcpyDeviceToHost, sc.s));
+    if (perm) RBL_HIP(hipMemcpyAsync(perm, sw.vals[0], sizeof(u32) * n, hipMemcpyDeviceToHost, sc.s));
+    RBL_HIP(hipStreamSynchronize(sc.s));
+    return RBL_OK;
+}
+
+static int k_pav_common(int loss, int64_t n, const double* sigma_a, const double* sigma_b, int ehrm, double B,
+                        double rho, const double* m_sorted, int branch_in, double* out, int64_t* n_merges,
+                        int* branch_out) {
+    Scratch sc;
+    RBL_TRY(scratch_begin(sc, nullptr));
+    if (n <= 0) return RBL_OK;
+    const int64_t nc = pav_num_chunks(n);
+    double* sa = sc.upload(sigma_a, (size_t)n);
+    double* sb = ehrm ? sc.upload(sigma_b, (size_t)n) : sa;
+    double* ms = sc.upload(m_sorted, (size_t)n);
+    double* u = sc.alloc<double>((size_t)n);
+    SC_CHECK(sa && sb && ms && u);
+    double* lx[3];
+    double* ch[3];
+    double* cph[3];
+    double* cpl[3];
+    for (int k = 0; k < 3; ++k) {
+        lx[k] = sc.alloc<double>((size_t)n + 1);
+        ch[k] = sc.alloc<double>((size_t)nc);
+        cph[k] = sc.alloc<double>((size_t)nc);
+        cpl[k] = sc.alloc<double>((size_t)nc);
+        SC_CHECK(lx[k] && ch[k] && cph[k] && cpl[k]);
+    }
+    SeamRec* recs = sc.alloc<SeamRec>((size_t)pav_num_recs(n));
+    u32* counters = sc.alloc<u32>(4);
+    double* partials = sc.alloc<double>((size_t)reduce_blocks() * 4);
+    int* branch = sc.alloc<int>(1);
+    SC_CHECK(recs && counters && partials && branch);
+    RBL_TRY(launch_prefix(sa, n, lx[0], ch[0], cph[0], cpl[0], sc.s));
+    RBL_TRY(launch_prefix(sb, n, lx[1], ch[1], cph[1], cpl[1], sc.s));
+    RBL_TRY(launch_prefix(ms, n, lx[2], ch[2], cph[2], cpl[2], sc.s));
+    Prefix pa{lx[0], cph[0], cpl[0]}, pb{lx[1], cph[1], cpl[1]}, pm{lx[2], cph[2], cpl[2]};
+    if (ehrm) {
+        RBL_TRY(launch_ehrm_branch(n, sa, sb, B, rho, ms, partials, branch, branch_in, sc.s));
+        RBL_TRY(launch_pav_init_ehrm(n, sa, sb, rho, ms, u, branch, sc.s));
+    } else {
+        RBL_TRY(launch_pav_init(loss, n, sa, rho, ms, u, sc.s));
+    }
+    RBL_TRY(launch_pav_tree(loss, n, rho, u, pa, pb, pm, ehrm ? branch : nullptr, recs, counters, sc.s));
+    // identity permutation scatter applies the EHRM clip
+    std::vector<u32> idh((size_t)n);
+    for (int64_t i = 0; i < n; ++i) idh[(size_t)i] = (u32)i;
+    u32* idd = sc.upload(idh.data(), (size_t)n);
+    double* zz = sc.alloc<double>((size_t)n);
+    SC_CHECK(idd && zz);
+    RBL_TRY(launch_scatter_z(n, u, idd, ehrm ? branch : nullptr, B, ehrm, rho, nullptr, zz, nullptr, 0, n, sc.s));
+    RBL_HIP(hipMemcpyAsync(out, zz, sizeof(double) * n, hipMemcpyDeviceToHost, sc.s));
+    unsigned mc = 0;
+    int br = -1;
+    RBL_HIP(hipMemcpyAsync(&mc, counters, sizeof(unsigned), hipMemcpyDeviceToHost, sc.s));
+    if (ehrm) RBL_HIP(hipMemcpyAsync(&br, branch, sizeof(int), hipMemcpyDeviceToHost, sc.s));
+    RBL_HIP(hipStreamSynchronize(sc.s));
+    if (n_merges) *n_merges = mc;
+    if (branch_out) *branch_out = br;
+    return RBL_OK;
+}
+
+int rbl_k_pav(int loss, int64_t n, const double* sigma, double rho, const double* m_sorted, double* out,
+              int64_t* n_merges) {
+    return k_pav_common(loss, n, sigma, sigma, 0, 0.0, rho, m_sorted, -1, out, n_merges, nullptr);
+}
+
+int rbl_k_pav_ehrm(int64_t n, const double* sigma_a, const double* sigma_b, double B, double rho,
+                   const double* m_sorted, int branch, double* out, int* branch_out) {
+    return k_pav_common(RBL_LOSS_BCE, n, sigma_a, sigma_b, 1, B, rho, m_sorted, branch, out, nullptr, branch_out);
+}
+
+int rbl_k_gemv(int storage, int64_t n, int64_t d, const double* D, const double* w, double* v) {
+    Scratch sc;
+    int num_cu = 256;
+    RBL_TRY(scratch_begin(sc, &num_cu));
+    if (n <= 0) return RBL_OK;
+    void* Dd = nullptr;
+    int64_t ld = 0;
+    RBL_TRY(upload_matrix(sc, storage, n, d, D, &Dd, &ld));
+    std::vector<double> wp((size_t)ld, 0.0);
+    for (int64_t j = 0; j < d; ++j) wp[(size_t)j] = w[j];
+    double* dw = sc.upload(wp.data(), (size_t)ld);
+    double* dv = sc.alloc<double>((size_t)n);
+    SC_CHECK(dw && dv);
+    RBL_TRY(launch_gemv(storage, Dd, n, ld, dw, dv, num_cu, sc.s));
+    RBL_HIP(hipMemcpyAsync(v, dv, sizeof(double) * n, hipMemcpyDeviceToHost, sc.s));
+    RBL_HIP(hipStreamSynchronize(sc.s));
+    return RBL_OK;
+}
+
+int rbl_k_gemvt(int storage, int64_t n, int64_t d, const double* D, const double* c, double* q) {
+    Scratch sc;
+    int num_cu = 256;
+    RBL_TRY(scratch_begin(sc, &num_cu));
+    void* Dd = nullptr;
+    int64_t ld = 0;
+    RBL_TRY(upload_matrix(sc, storage, n > 0 ? n : 0, d, D, &Dd, &ld));
+    double* dc = sc.upload(c, (size_t)n);
+    double* slab = sc.alloc<double>((size_t)gemvt_slab_rows(num_cu) * ld);
+    double* dq = sc.alloc<double>((size_t)ld);
+    SC_CHECK(dc && slab && dq);
+    RBL_TRY(launch_gemvt(storage, Dd, n, ld, dc, slab, dq, num_cu, sc.s));
+    RBL_HIP(hipMemcpyAsync(q, dq, sizeof(double) * d, hipMemcpyDeviceToHost, sc.s));
+    RBL_HIP(hipStreamSynchronize(sc.s));
+    return RBL_OK;
+}
+
+int rbl_k_gram(int storage, int64_t n, int64_t d, const double* D, double* G) {
+    Scratch sc;
+    int num_cu = 256;
+    RBL_TRY(scratch_begin(sc, &num_cu));
+    void* Dd = nullptr;
+    int64_t ld = 0;
+    RBL_TRY(upload_matrix(sc, storage, n, d, D, &Dd, &ld));
+    double* slab = (double*)sc.alloc<unsigned char>(gram_slab_bytes(ld, num_cu, n > 0 ? n : 1));
+    double* dG = sc.alloc<double>((size_t)ld * ld);
+    SC_CHECK(slab && dG);
+    RBL_TRY(launch_gram(storage, Dd, n, ld, d, slab, dG, num_cu, sc.s));
+    std::vector<double> hG((size_t)ld * ld);
+    RBL_HIP(hipMemcpyAsync(hG.data(), dG, sizeof(double) * ld * ld, hipMemcpyDeviceToHost, sc.s));
+    RBL_HIP(hipStreamSynchronize(sc.s));
+    for (int64_t i = 0; i < d; ++i)
+        for (int64_t j = 0; j < d; ++j) G[i * d + j] = hG[(size_t)(i * ld + j)];
+    return RBL_OK;
+}
+
+int rbl_k_wstep(int wstep, int64_t d, const double* G, const double* q, double rho, double reg, double smooth_t,
+                const double* w0, double tol, double* w_out, int* iters) {
+    Scratch sc;
+    RBL_TRY(scratch_begin(sc, nullptr));
+    const int64_t ld = round_up(d, 4);
+    std::vector<double> hG((size_t)ld * ld, 0.0), hq((size_t)ld, 0.0), hw((size_t)ld, 0.0);
+    for (int64_t i = 0; i < d; ++i) {
+        for (int64_t j = 0; j < d; ++j) hG[(size_t)(i * ld + j)] = G[i * d + j];
+        hq[(size_t)i] = q[i];
+        hw[(size_t)i] = w0 ? w0[i] : 0.0;
+    }
+    double* dG = sc.upload(hG.data(), hG.size());
+    double* dq = sc.upload(hq.data(), hq.size());
+    double* dw = sc.upload(hw.data(), hw.size());
+    SC_CHECK(dG && dq && dw);
+    WstepWorkspace ww{};
+    ww.yk = sc.alloc<double>((size_t)ld);
+    ww.Gy = sc.alloc<double>((size_t)ld);
+    ww.wn = sc.alloc<double>((size_t)ld);
+    ww.r = sc.alloc<double>((size_t)ld);
+    ww.p = sc.alloc<double>((size_t)ld);
+    ww.scal = sc.alloc<double>(8);
+    ww.flags = sc.alloc<int>(4);
+    SC_CHECK(ww.yk && ww.Gy && ww.wn && ww.r && ww.p && ww.scal && ww.flags);
+    double lam = 0.0;
+    RBL_TRY(launch_power_iteration(dG, ld, ww.yk, ww.Gy, ww.scal, 100, &lam, sc.s));
+    double L = 1.02 * lam;
+    if (!(L > 0.0)) L = 1.0;
+    int it = 0;
+    RBL_TRY(run_wstep(wstep, dG, ld, dq, rho, reg, smooth_t, L, tol > 0.0 ? tol : 1e-13, 100000, dw, ww, &it, sc.s));
+    RBL_HIP(hipMemcpyAsync(w_out, dw, sizeof(double) * d, hipMemcpyDeviceToHost, sc.s));
+    RBL_HIP(hipStreamSynchronize(sc.s));
+    if (iters) *iters = it;
+    return RBL_OK;
+}
+
+int rbl_k_weights(int weight_function, int64_t n, const double* args, int n_args, double* alphas, double* betas) {
+    Scratch sc;
+    RBL_TRY(scratch_begin(sc, nullptr));
+    if (weight_function < RBL_W_ERM || weight_function > RBL_W_EHRM) {
+        rbl_set_error("Unrecognized framework! Options: ['erm','extremile','superquantile','esrm','aorr','aorr_dc','ehrm']");
+        return RBL_ERR_INVALID;
+    }
+    if (weight_function != RBL_W_ERM && weight_function != RBL_W_EHRM) {
+        const int need = (weight_function == RBL_W_AORR || weight_function == RBL_W_AORR_DC) ? 2 : 1;
+        if (!args || n_args < need) {
+            rbl_set_error("args for framework is None!");
+            return RBL_ERR_INVALID;
+        }
+    }
+    double a2[2] = {args && n_args > 0 ? args[0] : 0.0, args && n_args > 1 ? args[1] : 0.0};
+    double* da = sc.alloc<double>((size_t)n);
+    double* db = sc.alloc<double>((size_t)n);
+    SC_CHECK(da && db);
+    RBL_TRY(launch_weights(weight_function, n, a2, da, db, sc.s));
+    if (alphas) RBL_HIP(hipMemcpyAsync(alphas, da, sizeof(double) * n, hipMemcpyDeviceToHost, sc.s));
+    if (betas) RBL_HIP(hipMemcpyAsync(betas, db, sizeof(double) * n, hipMemcpyDeviceToHost, sc.s));
+    RBL_HIP(hipStreamSynchronize(sc.s));
+    return RBL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,303 @@
+// elementwise.hip - n-vector kernels of the ADMM iteration: element prox (z-step for
+// erm), m = D w - lambda/rho, dual update + residual/objective partial sums, sigma
+// generators, and the objective from the cached v = D w.  All reductions are two-stage
+// with a fixed summation order (deterministic, no float atomics).
+#include "rbl_internal.h"
+#include "device_math.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+constexpr int RED_BLOCKS = 1024;  // fixed: partial sums do not depend on n or the device
+
+inline unsigned ew_grid(long long n) {
+    long long g = (n + EW_THREADS - 1) / EW_THREADS;
+    if (g < 1) g = 1;
+    if (g > 1 << 20) g = 1 << 20;
+    return (unsigned)g;
+}
+
+// erm: sigma is constant, the prox is monotone in m, so no sort and no PAV are needed:
+// z_i = prox(m_i) is the isotonic solution.  Fuses algorithms.py:89
+// (m), individual_solver.py:112-123 (prox) and the w-step's c = z + lambda/rho (:192).
+template <int LOSS>
+__global__ __launch_bounds__(EW_THREADS) void k_erm_zc(long long n, double sigma0, double rho,
+                                                        const double* __restrict__ v,
+                                                        const double* __restrict__ lam, double* __restrict__ m,
+                                                        double* __restrict__ z, double* __restrict__ c) {
+    const double inv_rho = 1.0 / rho;
+    for (long long i = (long long)blockIdx.x * EW_THREADS + threadIdx.x; i < n;
+         i += (long long)gridDim.x * EW_THREADS) {
+        double lr = lam[i] / rho;
+        double mi = v[i] - lr;
+        double zi = rbl::prox<LOSS>(sigma0, rho, mi);
+        m[i] = mi;
+        z[i] = zi;
+        c[i] = zi + lr;
+    }
+    (void)inv_rho;
+}
+
+__global__ void k_make_m(long long n, double rho, const double* __restrict__ v, const double* __restrict__ lam,
+                         double* __restrict__ m) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        m[i] = v[i] - lam[i] / rho;  // algorithms.py:89
+}
+
+__global__ void k_keys_from_m(long long n, const double* __restrict__ m, u64* __restrict__ keys,
+                              u32* __restrict__ idx) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        keys[i] = rbl::flip_key(m[i]);
+        if (idx) idx[i] = (u32)i;
+    }
+}
+
+template <int LOSS>
+__global__ __launch_bounds__(EW_THREADS) void k_prox(long long n, const double* __restrict__ sigma, double rho,
+                                                      const double* __restrict__ m, double* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * EW_THREADS + threadIdx.x; i < n;
+         i += (long long)gridDim.x * EW_THREADS)
+        out[i] = rbl::prox<LOSS>(sigma[i], rho, m[i]);
+}
+
+// lambda += rho (z - v) (algorithms.py:132); partials: sum (z-v)^2 (:135), sum loss(v)
+template <int LOSS>
+__global__ __launch_bounds__(EW_THREADS) void k_dual(long long n, double rho, const double* __restrict__ z,
+                                                      const double* __restrict__ v, double* __restrict__ lam,
+                                                      double* __restrict__ partials) {
+    __shared__ double smem[2 * EW_THREADS / 64];
+    double acc[2] = {0.0, 0.0};
+    for (long long i = (long long)blockIdx.x * EW_THREADS + threadIdx.x; i < n;
+         i += (long long)gridDim.x * EW_THREADS) {
+        double vi = v[i];
+        double r = z[i] - vi;
+        lam[i] = lam[i] + rho * r;
+        acc[0] += r * r;
+        acc[1] += rbl::sample_loss<LOSS>(vi);
+    }
+    rbl::block_sum<2, EW_THREADS>(acc, smem);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 2 + 0] = acc[0];
+        partials[blockIdx.x * 2 + 1] = acc[1];
+    }
+}
+
+// out[k] = sum_b partials[b*K + k], one block, fixed order
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partials, int nblocks, int K,
+                                                       double* __restrict__ out) {
+    __shared__ double smem[4];
+    for (int k = 0; k < K; ++k) {
+        double acc[1] = {0.0};
+        for (int b = threadIdx.x; b < nblocks; b += 256) acc[0] += partials[(long long)b * K + k];
+        rbl::block_sum<1, 256>(acc, smem);
+        if (threadIdx.x == 0) out[k] = acc[0];
+        __syncthreads();
+    }
+}
+
+__global__ void k_loss_keys(long long n, const double* __restrict__ v, u64* __restrict__ keys) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        keys[i] = rbl::flip_key(v[i]);
+}
+
+// sum_i sigma_i * loss(v_(i)) over ascending v (objective.py:73-81: losses are monotone
+// in v, so sorting v sorts the losses)
+template <int LOSS>
+__global__ __launch_bounds__(EW_THREADS) void k_sorted_loss_dot(long long n, const u64* __restrict__ keys,
+                                                                 const double* __restrict__ sigma,
+                                                                 double* __restrict__ partials) {
+    __shared__ double smem[EW_THREADS / 64];
+    double acc[1] = {0.0};
+    for (long long i = (long long)blockIdx.x * EW_THREADS + threadIdx.x; i < n;
+         i += (long long)gridDim.x * EW_THREADS)
+        acc[0] += sigma[i] * rbl::sample_loss<LOSS>(rbl::unflip_key(keys[i]));
+    rbl::block_sum<1, EW_THREADS>(acc, smem);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+template <int LOSS>
+__global__ __launch_bounds__(EW_THREADS) void k_loss_sum(long long n, const double* __restrict__ v, double scale,
+                                                          double* __restrict__ partials) {
+    __shared__ double smem[EW_THREADS / 64];
+    double acc[1] = {0.0};
+    for (long long i = (long long)blockIdx.x * EW_THREADS + threadIdx.x; i < n;
+         i += (long long)gridDim.x * EW_THREADS)
+        acc[0] += rbl::sample_loss<LOSS>(v[i]);
+    acc[0] *= scale;
+    rbl::block_sum<1, EW_THREADS>(acc, smem);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+// ---- sigma generators: src/optim/objective.py:97-164 ---------------------------------
+struct WeightParams {
+    int wf;
+    long long n;
+    double a0, a1;       // args
+    long long i0, i1;    // integer break points
+    double wa, wb;       // boundary / plateau weights
+};
+
+__device__ inline double distort(double p, double gamma) {
+    // objective.py:148-150
+    double pg = pow(p, gamma);
+    return pg / pow(pg + pow(1.0 - p, gamma), 1.0 / gamma);
+}
+
+__global__ void k_weights(WeightParams P, double* __restrict__ alphas, double* __restrict__ betas) {
+    const double nn = (double)P.n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P.n;
+         i += (long long)gridDim.x * blockDim.x) {
+        double x = (double)i, a = 0.0, b;
+        switch (P.wf) {
+            case RBL_W_ERM: a = 1.0 / nn; break;                                           // :97-98
+            case RBL_W_EXTREMILE: a = (pow(x + 1.0, P.a0) - pow(x, P.a0)) / pow(nn, P.a0); break;  // :101-105
+            case RBL_W_SUPERQUANTILE: a = (i < P.i0) ? 0.0 : (i == P.i0 ? P.wa : P.wb); break;     // :108-117
+            case RBL_W_ESRM:                                                                // :120-123
+                a = exp(-P.a0) * (exp(P.a0 * ((x + 1.0) / nn)) - exp(P.a0 * (x / nn))) / (1.0 - exp(-P.a0));
+                break;
+            case RBL_W_AORR: a = (i < P.i0 || i >= P.i1) ? 0.0 : (i == P.i0 ? P.wa : P.wb); break;  // :126-136
+            case RBL_W_AORR_DC:                                                             // :139-145
+                a = (i > P.i1 && i < P.i0) ? P.wb : 0.0;
+                if (i == P.i0 + 1) a = P.wa;
+                break;
+            default: break;
+        }
+        b = a;
+        if (P.wf == RBL_W_EHRM) {
+            a = distort((x + 1.0) / nn, 0.69) - distort(x / nn, 0.69);                // :153-157
+            b = distort((nn - x) / nn, 0.61) - distort((nn - x - 1.0) / nn, 0.61);    // :160-164
+        }
+        alphas[i] = a;
+        if (betas) betas[i] = b;
+    }
+}
+
+}  // namespace
+
+int reduce_blocks() { return RED_BLOCKS; }
+
+#define LAUNCH_LOSS(KERN, loss, grid, block, stream, ...)                                        \
+    do {                                                                                         \
+        if ((loss) == RBL_LOSS_BCE)                                                              \
+            hipLaunchKernelGGL((KERN<0>), dim3(grid), dim3(block), 0, stream, __VA_ARGS__);      \
+        else                                                                                     \
+            hipLaunchKernelGGL((KERN<1>), dim3(grid), dim3(block), 0, stream, __VA_ARGS__);      \
+    } while (0)
+
+int launch_erm_zc(int loss, int64_t n, double sigma0, double rho, const double* v, const double* lam, double* m,
+                  double* z, double* c, hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    LAUNCH_LOSS(k_erm_zc, loss, ew_grid(n), EW_THREADS, s, (long long)n, sigma0, rho, v, lam, m, z, c);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_make_m(int64_t n, double rho, const double* v, const double* lam, double* m, hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    hipLaunchKernelGGL(k_make_m, dim3(ew_grid(n)), dim3(256), 0, s, (long long)n, rho, v, lam, m);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_keys_from_m(int64_t n, const double* m, u64* keys, u32* idx, hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    hipLaunchKernelGGL(k_keys_from_m, dim3(ew_grid(n)), dim3(256), 0, s, (long long)n, m, keys, idx);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_prox(int loss, int64_t n, const double* sigma, double rho, const double* m, double* out, hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    LAUNCH_LOSS(k_prox, loss, ew_grid(n), EW_THREADS, s, (long long)n, sigma, rho, m, out);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_sum_partials(const double* partials, int nblocks, int K, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partials, nblocks, K, out);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_dual(int loss, int64_t n, double rho, const double* z, const double* v, double* lam, double* partials,
+                double* red, hipStream_t s) {
+    LAUNCH_LOSS(k_dual, loss, RED_BLOCKS, EW_THREADS, s, (long long)n, rho, z, v, lam, partials);
+    RBL_HIP(hipGetLastError());
+    return launch_sum_partials(partials, RED_BLOCKS, 2, red, s);
+}
+
+int launch_loss_keys(int64_t n, const double* v, u64* keys, hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    hipLaunchKernelGGL(k_loss_keys, dim3(ew_grid(n)), dim3(256), 0, s, (long long)n, v, keys);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_sorted_loss_dot(int loss, int64_t n, const u64* sorted_keys, const double* sigma, double* partials,
+                           double* out, hipStream_t s) {
+    LAUNCH_LOSS(k_sorted_loss_dot, loss, RED_BLOCKS, EW_THREADS, s, (long long)n, sorted_keys, sigma, partials);
+    RBL_HIP(hipGetLastError());
+    return launch_sum_partials(partials, RED_BLOCKS, 1, out, s);
+}
+
+int launch_loss_sum(int loss, int64_t n, const double* v, double scale, double* partials, double* out,
+                    hipStream_t s) {
+    LAUNCH_LOSS(k_loss_sum, loss, RED_BLOCKS, EW_THREADS, s, (long long)n, v, scale, partials);
+    RBL_HIP(hipGetLastError());
+    return launch_sum_partials(partials, RED_BLOCKS, 1, out, s);
+}
+
+int launch_weights(int wf, int64_t n, const double* args, double* alphas, double* betas, hipStream_t s) {
+    WeightParams P;
+    P.wf = wf;
+    P.n = n;
+    P.a0 = args ? args[0] : 0.0;
+    P.a1 = args ? args[1] : 0.0;
+    P.i0 = P.i1 = 0;
+    P.wa = P.wb = 0.0;
+    const double nn = (double)n;
+    if (wf == RBL_W_SUPERQUANTILE) {  // objective.py:108-117
+        double q = P.a0;
+        long long idx = (long long)floor(nn * q);
+        double frac = 1.0 - (nn - (double)idx - 1.0) / (nn * (1.0 - q));
+        P.i0 = idx;
+        if (frac > 1e-12) {
+            P.wa = frac;
+            P.wb = 1.0 / (nn * (1.0 - q));
+        } else {
+            P.wa = P.wb = 1.0 / (nn - (double)idx);
+        }
+    } else if (wf == RBL_W_AORR) {  // objective.py:126-136
+        double ql = P.a0, qu = P.a1;
+        long long lo = (long long)floor(nn * ql), up = (long long)floor(nn * qu);
+        double frac = 1.0 - ((double)up - (double)lo - 1.0) / (nn * (qu - ql));
+        P.i0 = lo;
+        P.i1 = up;
+        if (frac > 1e-12) {
+            P.wa = frac;
+            P.wb = 1.0 / (nn * (qu - ql));
+        } else {
+            P.wa = P.wb = 1.0 / ((double)up - (double)lo);
+        }
+    } else if (wf == RBL_W_AORR_DC) {  // objective.py:139-145 (k = args[0], m = args[1])
+        long long k = (long long)P.a0, mm = (long long)P.a1;
+        if (k <= mm) {
+            rbl_set_error("need args[0] > args[1]!");
+            return RBL_ERR_INVALID;
+        }
+        if (k + 1 >= n) {
+            rbl_set_error("aorr_dc needs args[0] + 1 < n");
+            return RBL_ERR_INVALID;
+        }
+        P.i0 = k;
+        P.i1 = mm;
+        P.wb = 1.0 / (double)(k - mm);
+        P.wa = 1.0 - (double)(k - mm - 1) / (double)(k - mm);
+    }
+    hipLaunchKernelGGL(k_weights, dim3(ew_grid(n)), dim3(256), 0, s, P, alphas, betas);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}

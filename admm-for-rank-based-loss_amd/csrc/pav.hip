@@ -1,0 +1,384 @@
+// pav.hip - exact generalised pool-adjacent-violators on the GPU (z-step,
+// src/optim/algorithms.py:95-104 -> src/util/pav.py:93-178 / src/util/PAV_cpt.py:234-293).
+//
+// The reference merges decreasing runs sweep after sweep (O(n) sweeps in bad cases,
+// SURVEY 3.4-i).  The isotonic solution is unique, so this file computes it with a
+// bottom-up merge tree instead (restated on the CPU in oracle/pav.py:pav_tree_exact):
+//   * u[i] starts as the element prox of sorted position i (every position is a solved
+//     segment of length 1);
+//   * level L joins the solved segments [k*2^L, k*2^L + 2^(L-1)) and the next 2^(L-1)
+//     positions.  Joining two solved neighbours pools exactly ONE block around the seam:
+//     the left positions with u > x* and the right positions with u < x*, where x* is the
+//     root of the increasing, continuous function
+//         Psi(t) = sum_{i in A(t)} f_i'(t),   A(t) = {left: u_i > t} U {right: u_i < t},
+//         f_i'(t) = sigma_i * loss'(t) + rho * (t - m_i).
+//     The extents are found by binary search on the sign of Psi at existing values of u
+//     (each evaluation: two binary searches on the monotone halves + prefix-sum lookups),
+//     the pooled block is solved once, and u is overwritten on the pooled range.
+// Block sums come from two-level prefix sums (1024-position chunks, chunk totals kept in
+// double-double) so a small block's sum is not a difference of two n-sized prefixes.
+#include "rbl_internal.h"
+#include "device_math.h"
+
+namespace {
+
+constexpr int PV_THREADS = 256;
+constexpr long long SELF_FILL_MAX_HALF = 512;  // seams of segments up to this size fill their own range
+
+inline unsigned pv_grid(long long n, int threads = PV_THREADS, long long cap = 1 << 20) {
+    long long g = (n + threads - 1) / threads;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// ---------------------------------------------------------------- prefix sums
+// locx[i] = sum of x over [chunk_start(i), i); chunk_tot[c] = sum of chunk c.  One block
+// per 1024-chunk, 256 threads x 4 consecutive elements.  Positions 0..n inclusive.
+__global__ __launch_bounds__(256) void k_chunk_scan(const double* __restrict__ x, long long n,
+                                                     double* __restrict__ locx, double* __restrict__ chunk_tot) {
+    __shared__ double wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long base = (long long)blockIdx.x * PAV_CHUNK + tid * 4;
+    double a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = (base + k < n) ? x[base + k] : 0.0;
+    double tsum = (a[0] + a[1]) + (a[2] + a[3]);
+    double incl = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        double y = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += y;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    double pre = incl - tsum;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    double run = pre;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k <= n) locx[base + k] = run;
+        run += a[k];
+    }
+    if (tid == 255) chunk_tot[blockIdx.x] = run;
+}
+
+__device__ inline void two_sum(double a, double b, double& s, double& e) {
+    s = a + b;
+    double bb = s - a;
+    e = (a - (s - bb)) + (b - bb);
+}
+__device__ inline void dd_add(double ah, double al, double bh, double bl, double& ch, double& cl) {
+    double s, e;
+    two_sum(ah, bh, s, e);
+    e += al + bl;
+    ch = s + e;
+    cl = e - (ch - s);
+}
+
+// double-double exclusive scan of the chunk totals, one block of 1024 threads
+__global__ __launch_bounds__(1024) void k_chunk_prefix_dd(const double* __restrict__ chunk_tot, long long nc,
+                                                           double* __restrict__ cph, double* __restrict__ cpl) {
+    __shared__ double sh[1024], sl[1024];
+    const int tid = threadIdx.x;
+    const long long per = (nc + 1023) / 1024;
+    const long long b = tid * per;
+    long long e = b + per;
+    if (e > nc) e = nc;
+    double h = 0.0, l = 0.0;
+    for (long long i = b; i < e; ++i) dd_add(h, l, chunk_tot[i], 0.0, h, l);
+    sh[tid] = h;
+    sl[tid] = l;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        double oh = 0.0, ol = 0.0;
+        if (tid >= off) {
+            oh = sh[tid - off];
+            ol = sl[tid - off];
+        }
+        __syncthreads();
+        if (tid >= off) {
+            dd_add(sh[tid], sl[tid], oh, ol, h, l);
+            sh[tid] = h;
+            sl[tid] = l;
+        }
+        __syncthreads();
+    }
+    // exclusive prefix of this thread's first chunk
+    double ph = 0.0, pl = 0.0;
+    if (tid > 0) {
+        ph = sh[tid - 1];
+        pl = sl[tid - 1];
+    }
+    for (long long i = b; i < e; ++i) {
+        cph[i] = ph;
+        cpl[i] = pl;
+        dd_add(ph, pl, chunk_tot[i], 0.0, ph, pl);
+    }
+}
+
+__device__ inline double range_sum(const Prefix& p, long long s, long long e1) {
+    // sum over sorted positions [s, e1)
+    const long long cs = s >> PAV_CHUNK_LOG, ce = e1 >> PAV_CHUNK_LOG;
+    double r = p.locx[e1] - p.locx[s];
+    if (ce != cs) r += (p.cph[ce] - p.cph[cs]) + (p.cpl[ce] - p.cpl[cs]);
+    return r;
+}
+
+// ---------------------------------------------------------------- block value / sign
+template <int LOSS>
+__device__ inline double block_value(double ssig, double sm, double cnt, double rho) {
+    // src/util/pav.py:134-140: solve with (sum sigma / len, sum m / len)
+    return rbl::prox<LOSS>(ssig / cnt, rho, sm / cnt);
+}
+
+// sign of the pooled derivative of positions [s, e] at t:  >0 <=> pooled value < t
+template <int LOSS>
+__device__ inline double psi_sign(const Prefix& pa, const Prefix& pm, double rho, long long s, long long e, double t) {
+    if (e < s) return 0.0;
+    const double A = range_sum(pa, s, e + 1), M = range_sum(pm, s, e + 1), cnt = (double)(e + 1 - s);
+    if (LOSS == 0) return A * rbl::sigmoid1(t) + rho * (cnt * t - M);
+    return t - block_value<1>(A, M, cnt, rho);
+}
+
+__device__ inline long long upper_bound_gt(const double* u, long long lo, long long hi, double t) {
+    // first i in [lo, hi) with u[i] > t (hi if none); u non-decreasing on [lo, hi)
+    while (lo < hi) {
+        long long mid = lo + ((hi - lo) >> 1);
+        if (u[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+__device__ inline long long lower_bound_ge(const double* u, long long lo, long long hi, double t) {
+    // first j in [lo, hi) with u[j] >= t (hi if none)
+    while (lo < hi) {
+        long long mid = lo + ((hi - lo) >> 1);
+        if (u[mid] >= t) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// One thread per seam of a level.  half = 2^(L-1).
+template <int LOSS>
+__global__ __launch_bounds__(PV_THREADS) void k_pav_seam(double* __restrict__ u, long long n, long long half,
+                                                          Prefix pa_, Prefix pb_, Prefix pm, const int* branch,
+                                                          double rho, SeamRec* __restrict__ recs,
+                                                          long long nseams, u32* __restrict__ merge_counter,
+                                                          int self_fill) {
+    const long long k = (long long)blockIdx.x * PV_THREADS + threadIdx.x;
+    if (k >= nseams) return;
+    const long long seam = (2 * k + 1) * half;
+    if (seam >= n) {
+        if (!self_fill) recs[k].s = -1;
+        return;
+    }
+    if (u[seam - 1] <= u[seam]) {  // pav.py:105 - only a strict decrease is a violation
+        if (!self_fill) recs[k].s = -1;
+        return;
+    }
+    const Prefix pa = (branch && *branch) ? pb_ : pa_;
+    const long long L0 = seam - half;
+    long long R1 = seam + half;
+    if (R1 > n) R1 = n;
+
+    // s* = first left position whose value exceeds x*  <=>  first i with Psi(u[i]) > 0
+    long long lo = L0, hi = seam - 1;
+    while (lo < hi) {
+        const long long mid = lo + ((hi - lo) >> 1);
+        const double t = u[mid];
+        const long long s = upper_bound_gt(u, mid + 1, seam, t);
+        const long long e = lower_bound_ge(u, seam, R1, t) - 1;
+        if (psi_sign<LOSS>(pa, pm, rho, s, e, t) > 0.0) hi = mid; else lo = mid + 1;
+    }
+    const long long s_star = lo;
+    // e* = last right position whose value is below x*  <=>  last j with Psi(u[j]) < 0
+    lo = seam;
+    hi = R1 - 1;
+    while (lo < hi) {
+        const long long mid = lo + ((hi - lo + 1) >> 1);
+        const double t = u[mid];
+        const long long s = upper_bound_gt(u, L0, seam, t);
+        const long long e = lower_bound_ge(u, seam, mid, t) - 1;
+        if (psi_sign<LOSS>(pa, pm, rho, s, e, t) < 0.0) lo = mid; else hi = mid - 1;
+    }
+    const long long e_star = lo;
+    const double A = range_sum(pa, s_star, e_star + 1), M = range_sum(pm, s_star, e_star + 1);
+    const double x = block_value<LOSS>(A, M, (double)(e_star + 1 - s_star), rho);
+    atomicAdd(merge_counter, 1u);
+    if (self_fill) {
+        for (long long i = s_star; i <= e_star; ++i) u[i] = x;
+    } else {
+        recs[k].s = s_star;
+        recs[k].e = e_star;
+        recs[k].x = x;
+    }
+}
+
+__global__ void k_pav_fill(double* __restrict__ u, long long n, int level_shift, const SeamRec* __restrict__ recs) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const SeamRec r = recs[i >> level_shift];
+        if (r.s >= 0 && i >= r.s && i <= r.e) u[i] = r.x;
+    }
+}
+
+// ---------------------------------------------------------------- setup kernels
+__global__ void k_unflip(long long n, const u64* __restrict__ keys, double* __restrict__ ms) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        ms[i] = rbl::unflip_key(keys[i]);
+}
+
+template <int LOSS>
+__global__ __launch_bounds__(PV_THREADS) void k_pav_init(long long n, const double* __restrict__ sigma, double rho,
+                                                          const double* __restrict__ ms, double* __restrict__ u) {
+    for (long long i = (long long)blockIdx.x * PV_THREADS + threadIdx.x; i < n;
+         i += (long long)gridDim.x * PV_THREADS)
+        u[i] = rbl::prox<LOSS>(sigma[i], rho, ms[i]);
+}
+
+__global__ __launch_bounds__(PV_THREADS) void k_pav_init_ehrm(long long n, const double* __restrict__ sa,
+                                                               const double* __restrict__ sb, double rho,
+                                                               const double* __restrict__ ms, double* __restrict__ u,
+                                                               const int* __restrict__ branch) {
+    const double* sg = (*branch) ? sb : sa;
+    for (long long i = (long long)blockIdx.x * PV_THREADS + threadIdx.x; i < n;
+         i += (long long)gridDim.x * PV_THREADS)
+        u[i] = rbl::prox_bce(sg[i], rho, ms[i]);
+}
+
+// EHRM singleton-stage scalar test (src/util/PAV_cpt.py:205-226): opt1 = min(prox_a, B),
+// opt2 = max(prox_b, B); fval_k = sum sigma_k*log(1+exp(opt_k)) + rho/2 ||opt_k - m||^2
+__global__ __launch_bounds__(PV_THREADS) void k_ehrm_fvals(long long n, const double* __restrict__ sa,
+                                                            const double* __restrict__ sb, double B, double rho,
+                                                            const double* __restrict__ ms,
+                                                            double* __restrict__ partials) {
+    __shared__ double smem[2 * PV_THREADS / 64];
+    double acc[2] = {0.0, 0.0};
+    for (long long i = (long long)blockIdx.x * PV_THREADS + threadIdx.x; i < n;
+         i += (long long)gridDim.x * PV_THREADS) {
+        const double m = ms[i];
+        double o1 = rbl::prox_bce(sa[i], rho, m);
+        if (o1 > B) o1 = B;
+        double o2 = rbl::prox_bce(sb[i], rho, m);
+        if (o2 <= B) o2 = B;
+        acc[0] += sa[i] * rbl::softplus(o1) + 0.5 * rho * (o1 - m) * (o1 - m);
+        acc[1] += sb[i] * rbl::softplus(o2) + 0.5 * rho * (o2 - m) * (o2 - m);
+    }
+    rbl::block_sum<2, PV_THREADS>(acc, smem);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 2 + 0] = acc[0];
+        partials[blockIdx.x * 2 + 1] = acc[1];
+    }
+}
+
+__global__ void k_ehrm_pick(const double* __restrict__ partials, int nblocks, int forced, int* __restrict__ branch) {
+    __shared__ double smem[8];
+    double acc[2] = {0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        acc[0] += partials[b * 2 + 0];
+        acc[1] += partials[b * 2 + 1];
+    }
+    rbl::block_sum<2, 256>(acc, smem);
+    if (threadIdx.x == 0) *branch = (forced >= 0) ? forced : ((acc[0] <= acc[1]) ? 0 : 1);  // PAV_cpt.py:225-226
+}
+
+// z[perm[i]] = clip(u[i]); c = z + lambda/rho  (algorithms.py:103-104 and :192)
+__global__ void k_scatter_z(long long n, const double* __restrict__ u, const u32* __restrict__ perm,
+                            const int* __restrict__ branch, double B, int has_B, double rho,
+                            const double* __restrict__ lam, double* __restrict__ z, double* __restrict__ c,
+                            long long off, long long nloc) {
+    const int br = (has_B && branch) ? *branch : -1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long g = perm[i];
+        if (g < off || g >= off + nloc) continue;
+        double x = u[i];
+        if (br == 0) x = fmin(x, B);       // branch a: all z <= B  (PAV_cpt.py:211)
+        else if (br == 1) x = fmax(x, B);  // branch b: all z >= B  (PAV_cpt.py:218)
+        const long long l = g - off;
+        z[l] = x;
+        if (c) c[l] = x + lam[l] / rho;
+    }
+}
+
+}  // namespace
+
+int64_t pav_num_chunks(int64_t n) { return n / PAV_CHUNK + 1; }
+int64_t pav_num_recs(int64_t n) { return n / (2 * SELF_FILL_MAX_HALF) + 2; }
+
+int launch_prefix(const double* x, int64_t n, double* locx, double* chunk_tot, double* cph, double* cpl,
+                  hipStream_t s) {
+    const long long nc = pav_num_chunks(n);
+    hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)nc), dim3(256), 0, s, x, (long long)n, locx, chunk_tot);
+    hipLaunchKernelGGL(k_chunk_prefix_dd, dim3(1), dim3(1024), 0, s, chunk_tot, nc, cph, cpl);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_unflip_keys(int64_t n, const u64* keys, double* ms, hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    hipLaunchKernelGGL(k_unflip, dim3(pv_grid(n)), dim3(256), 0, s, (long long)n, keys, ms);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_pav_init(int loss, int64_t n, const double* sigma, double rho, const double* ms, double* u,
+                    hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    if (loss == RBL_LOSS_BCE)
+        hipLaunchKernelGGL(k_pav_init<0>, dim3(pv_grid(n)), dim3(PV_THREADS), 0, s, (long long)n, sigma, rho, ms, u);
+    else
+        hipLaunchKernelGGL(k_pav_init<1>, dim3(pv_grid(n)), dim3(PV_THREADS), 0, s, (long long)n, sigma, rho, ms, u);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_ehrm_branch(int64_t n, const double* sa, const double* sb, double B, double rho, const double* ms,
+                       double* partials, int* branch, int forced, hipStream_t s) {
+    const int nb = reduce_blocks();
+    hipLaunchKernelGGL(k_ehrm_fvals, dim3(nb), dim3(PV_THREADS), 0, s, (long long)n, sa, sb, B, rho, ms, partials);
+    hipLaunchKernelGGL(k_ehrm_pick, dim3(1), dim3(256), 0, s, partials, nb, forced, branch);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_pav_init_ehrm(int64_t n, const double* sa, const double* sb, double rho, const double* ms, double* u,
+                         const int* branch, hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    hipLaunchKernelGGL(k_pav_init_ehrm, dim3(pv_grid(n)), dim3(PV_THREADS), 0, s, (long long)n, sa, sb, rho, ms, u,
+                       branch);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_pav_tree(int loss, int64_t n, double rho, double* u, Prefix pa, Prefix pb, Prefix pm, const int* branch,
+                    SeamRec* recs, u32* merge_counter, hipStream_t s) {
+    RBL_HIP(hipMemsetAsync(merge_counter, 0, sizeof(u32), s));
+    int level = 1;
+    for (long long half = 1; half < n; half <<= 1, ++level) {
+        const long long nseams = (n + 2 * half - 1) / (2 * half);
+        const int self_fill = half <= SELF_FILL_MAX_HALF ? 1 : 0;
+        const unsigned grid = pv_grid(nseams, PV_THREADS, 1LL << 30);
+        if (loss == RBL_LOSS_BCE)
+            hipLaunchKernelGGL(k_pav_seam<0>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, half, pa, pb, pm,
+                               branch, rho, recs, nseams, merge_counter, self_fill);
+        else
+            hipLaunchKernelGGL(k_pav_seam<1>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, half, pa, pb, pm,
+                               branch, rho, recs, nseams, merge_counter, self_fill);
+        if (!self_fill)
+            hipLaunchKernelGGL(k_pav_fill, dim3(pv_grid(n)), dim3(256), 0, s, u, (long long)n, level, recs);
+    }
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_scatter_z(int64_t n, const double* u, const u32* perm, const int* branch, double B, int has_B,
+                     double rho, const double* lam, double* z, double* c, int64_t off, int64_t nloc,
+                     hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    hipLaunchKernelGGL(k_scatter_z, dim3(pv_grid(n)), dim3(256), 0, s, (long long)n, u, perm, branch, B, has_B, rho,
+                       lam, z, c, (long long)off, (long long)nloc);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}

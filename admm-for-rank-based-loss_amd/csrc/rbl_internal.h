@@ -1,0 +1,161 @@
+// rbl_internal.h - shared declarations of librbl.so (gfx950 only, no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include "../../include/rbl.h"
+
+void rbl_set_error(const char* fmt, ...);
+
+#define RBL_HIP(x)                                                                         \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            rbl_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            return RBL_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define RBL_TRY(x)                 \
+    do {                           \
+        int r_ = (x);              \
+        if (r_ != RBL_OK) return r_; \
+    } while (0)
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int RBL_WAVE = 64;
+constexpr int PAV_CHUNK_LOG = 10;              // prefix-sum chunk = 1024 sorted positions
+constexpr int PAV_CHUNK = 1 << PAV_CHUNK_LOG;
+
+// ---- two-level prefix sums over sorted positions (pav.hip) -------------------------
+// P(i) = sum_{j<i} x_j = (cph[i>>10] + cpl[i>>10]) + locx[i]; locx restarts at every
+// 1024-chunk so that small-block sums do not cancel against n-sized prefixes.
+struct Prefix {
+    const double* locx;  // n+1 entries, exclusive prefix inside the chunk
+    const double* cph;   // chunk-level exclusive prefix, double-double high part
+    const double* cpl;   //                               double-double low part
+};
+
+struct SeamRec {
+    long long s;  // first pooled position, -1: no merge
+    long long e;  // last pooled position
+    double x;     // pooled value
+};
+
+// ---- sweep.hip ------------------------------------------------------------------------
+// v = D w : D is n x ld row-major (ld % 4 == 0, columns >= d are zero)
+int launch_gemv(int storage, const void* D, int64_t n, int64_t ld, const double* w, double* v,
+                int num_cu, hipStream_t s);
+// q = D^T c : partial column sums go to slab (gemvt_slab_rows() x ld doubles), then q
+int gemvt_slab_rows(int num_cu);
+int launch_gemvt(int storage, const void* D, int64_t n, int64_t ld, const double* c, double* slab,
+                 double* q, int num_cu, hipStream_t s);
+// D[r0+i][j] = -y[i] * X[i][j] for a chunk of rows already on the device (fp64 staging)
+int launch_form_D(int storage, void* D, int64_t ld, int64_t row0, const double* Xdev, int64_t ldx,
+                  const double* ydev, int64_t rows, int64_t d, hipStream_t s);
+int launch_D_to_f64(int storage, const void* D, int64_t ld, int64_t n, int64_t d, double* out,
+                    hipStream_t s);
+// column sums / sums of squares (slab-reduced, deterministic) and in-place standardisation
+int launch_colstats(int storage, const void* D, int64_t n, int64_t ld, double* slab, double* sum,
+                    double* sumsq, int num_cu, hipStream_t s);
+int launch_standardize_negy(int storage, void* D, int64_t n, int64_t ld, int64_t d, const double* mean,
+                            const double* inv_std, const signed char* ysign, hipStream_t s);
+
+// ---- elementwise.hip --------------------------------------------------------------------
+int launch_erm_zc(int loss, int64_t n, double sigma0, double rho, const double* v, const double* lam,
+                  double* m, double* z, double* c, hipStream_t s);
+int launch_make_m(int64_t n, double rho, const double* v, const double* lam, double* m, hipStream_t s);
+int launch_keys_from_m(int64_t n, const double* m, u64* keys, u32* idx, hipStream_t s);
+int launch_prox(int loss, int64_t n, const double* sigma, double rho, const double* m, double* out,
+                hipStream_t s);
+// lambda += rho (z - v); partial sums {sum (z-v)^2, sum loss(v)} -> red[0..1]
+int launch_dual(int loss, int64_t n, double rho, const double* z, const double* v, double* lam,
+                double* partials, double* red, hipStream_t s);
+int launch_weights(int wf, int64_t n, const double* args, double* alphas, double* betas, hipStream_t s);
+// generic deterministic two-stage reduction helpers
+int reduce_blocks();
+int launch_sum_partials(const double* partials, int nblocks, int K, double* out, hipStream_t s);
+// losses of v (for the objective), optionally as sortable keys
+int launch_loss_keys(int64_t n, const double* v, u64* keys, hipStream_t s);
+int launch_sorted_loss_dot(int loss, int64_t n, const u64* sorted_keys, const double* sigma,
+                           double* partials, double* out, hipStream_t s);
+int launch_loss_sum(int loss, int64_t n, const double* v, double scale, double* partials, double* out,
+                    hipStream_t s);
+
+// ---- sort.hip -------------------------------------------------------------------------
+struct SortWorkspace {
+    u64* keys[2];
+    u32* vals[2];
+    u32* spine;      // 256 * RS_MAX_BLOCKS
+    u32* bin_total;  // 256
+    u32* bin_base;   // 256
+};
+size_t sort_spine_bytes();
+// sorts keys[0]/vals[0] ascending (stable); result ends in keys[0]/vals[0]
+int launch_radix_sort(SortWorkspace& ws, int64_t n, bool with_vals, hipStream_t s);
+
+// ---- pav.hip ----------------------------------------------------------------------------
+struct PavWorkspace {
+    double* ms;        // n   sorted m
+    double* u;         // n   current block values by sorted position
+    double* locx_m;    // n+1
+    double* chunk_m;   // nchunks
+    double* cph_m;     // nchunks
+    double* cpl_m;     // nchunks
+    SeamRec* recs;     // seams of the upper levels
+    u32* counters;     // [0] merges
+    double* partials;  // reduce scratch
+    int* branch;       // EHRM branch flag on the device (0 = a, 1 = b)
+};
+int64_t pav_num_chunks(int64_t n);
+int64_t pav_num_recs(int64_t n);
+int launch_prefix(const double* x, int64_t n, double* locx, double* chunk_tot, double* cph, double* cpl,
+                  hipStream_t s);
+int launch_unflip_keys(int64_t n, const u64* keys, double* ms, hipStream_t s);
+// u = prox(sigma_i, ms_i) per sorted position
+int launch_pav_init(int loss, int64_t n, const double* sigma, double rho, const double* ms, double* u,
+                    hipStream_t s);
+// EHRM: scalar branch test (PAV_cpt.py:205-226) -> *branch, then u = prox(sigma_branch, ms)
+int launch_ehrm_branch(int64_t n, const double* sa, const double* sb, double B, double rho, const double* ms,
+                       double* partials, int* branch, int forced, hipStream_t s);
+int launch_pav_init_ehrm(int64_t n, const double* sa, const double* sb, double rho, const double* ms,
+                         double* u, const int* branch, hipStream_t s);
+// merge tree over u; sigma prefix: pa (or pa/pb selected by *branch when branch != nullptr)
+int launch_pav_tree(int loss, int64_t n, double rho, double* u, Prefix pa, Prefix pb, Prefix pm,
+                    const int* branch, SeamRec* recs, u32* merge_counter, hipStream_t s);
+// z[perm[i]] = clip(u[i]); c[perm[i]] = z + lam[perm[i]]/rho  (local slice [off, off+nloc))
+int launch_scatter_z(int64_t n, const double* u, const u32* perm, const int* branch, double B, int has_B,
+                     double rho, const double* lam, double* z, double* c, int64_t off, int64_t nloc,
+                     hipStream_t s);
+
+// ---- wstep.hip --------------------------------------------------------------------------
+struct WstepWorkspace {
+    double* yk;     // d
+    double* Gy;     // d
+    double* wn;     // d
+    double* r;      // d (CG)
+    double* p;      // d (CG)
+    double* scal;   // small device scalars: [0]=t, [1]=rr, ...
+    int* flags;     // [0]=done, [1]=iters
+};
+int launch_power_iteration(const double* G, int64_t d, double* tmp1, double* tmp2, double* scal, int iters,
+                           double* lambda_host, hipStream_t s);
+// lasso / smoothed-l1 by FISTA with restart, ridge by CG; w is updated in place.
+int run_wstep(int wstep, const double* G, int64_t d, const double* q, double rho, double reg, double smooth_t,
+              double L, double tol, int max_inner, double* w, WstepWorkspace& ws, int* iters_host,
+              hipStream_t s);
+int launch_diffnorm2(int64_t d, const double* a, const double* b, double* out, hipStream_t s);
+int launch_reg_terms(int64_t d, const double* w, double* out2 /* [sum w^2, sum |w|] */, hipStream_t s);
+int launch_soft_threshold(int64_t d, double* w, double t, hipStream_t s);
+
+// ---- gram.hip ---------------------------------------------------------------------------
+size_t gram_slab_bytes(int64_t d, int num_cu, int64_t n);
+int launch_gram(int storage, const void* D, int64_t n, int64_t ld, int64_t d, double* slab, double* G,
+                int num_cu, hipStream_t s);
+
+// ---- synth.hip --------------------------------------------------------------------------
+int launch_synth(int storage, void* D, int64_t n, int64_t ld, int64_t d, int64_t row_offset, u64 seed,
+                 double class_sep, double flip_y, const int* colperm, const double* mix, signed char* ysign,
+                 hipStream_t s);

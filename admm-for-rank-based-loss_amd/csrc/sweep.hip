@@ -1,0 +1,475 @@
+// sweep.hip - the two HBM-bound streaming passes over the n x d matrix D = -y*X that
+// every ADMM iteration needs:
+//   v = D w      replaces the three GEMVs of src/optim/algorithms.py:89,132,135
+//   q = D^T c    replaces the n-space sweeps of src/util/fast_lasso.py:41,43,55 and
+//                src/util/w_LBFGS.py:34,43 (the w-step then runs in d-space on G = D^T D)
+// D is row-major, ld % 4 == 0, stored fp32 (default) or fp64; accumulation is fp64.
+// Both kernels read D exactly once with 16-byte per-lane loads (1 KiB per wave
+// instruction); they are memory bound: algorithmic bytes = n*ld*sizeof(T) per launch.
+#include "rbl_internal.h"
+
+namespace {
+
+template <typename T> struct Pkt;  // one 16-byte packet
+template <> struct Pkt<float> {
+    static constexpr int E = 4;
+    typedef float4 type;
+    __device__ static inline void fma(const float4& p, const double* w, double& acc) {
+        acc = __builtin_fma((double)p.x, w[0], acc);
+        acc = __builtin_fma((double)p.y, w[1], acc);
+        acc = __builtin_fma((double)p.z, w[2], acc);
+        acc = __builtin_fma((double)p.w, w[3], acc);
+    }
+    __device__ static inline void axpy(const float4& p, double c, double* acc) {
+        acc[0] = __builtin_fma((double)p.x, c, acc[0]);
+        acc[1] = __builtin_fma((double)p.y, c, acc[1]);
+        acc[2] = __builtin_fma((double)p.z, c, acc[2]);
+        acc[3] = __builtin_fma((double)p.w, c, acc[3]);
+    }
+};
+template <> struct Pkt<double> {
+    static constexpr int E = 2;
+    typedef double2 type;
+    __device__ static inline void fma(const double2& p, const double* w, double& acc) {
+        acc = __builtin_fma(p.x, w[0], acc);
+        acc = __builtin_fma(p.y, w[1], acc);
+    }
+    __device__ static inline void axpy(const double2& p, double c, double* acc) {
+        acc[0] = __builtin_fma(p.x, c, acc[0]);
+        acc[1] = __builtin_fma(p.y, c, acc[1]);
+    }
+};
+
+__device__ inline double shfl_xor_d(double x, int mask) {
+    return __shfl_xor(x, mask, 64);
+}
+
+// ------------------------------------------------------------------------------ v = D w
+// LPR lanes share one row (power of two <= 64); a wave covers 64/LPR rows per pass and
+// keeps U row-groups in flight.  P = passes of LPR packets per row, compile-time so the
+// U*P loads of a step are issued back to back and w lives in registers; P == 0 selects
+// the generic path (w staged in LDS, run-time pass loop) for large d.
+template <typename T, int LPR, int P, int U>
+__global__ __launch_bounds__(256) void k_gemv(const T* __restrict__ D, long long n, long long ld,
+                                                 const double* __restrict__ w, double* __restrict__ v) {
+    typedef typename Pkt<T>::type pkt_t;
+    constexpr int E = Pkt<T>::E;
+    constexpr int RPW = 64 / LPR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane % LPR, rsub = lane / LPR;
+    const long long PK = ld / E;
+    const long long rows_per_step = (long long)RPW * U;
+    const long long stride = (long long)gridDim.x * 4 * rows_per_step;
+
+    double wr[P > 0 ? P : 1][E];
+    extern __shared__ double sw[];
+    if (P > 0) {
+#pragma unroll
+        for (int p = 0; p < (P > 0 ? P : 1); ++p) {
+            long long pk = sub + (long long)p * LPR;
+#pragma unroll
+            for (int k = 0; k < E; ++k) wr[p][k] = (pk < PK) ? w[pk * E + k] : 0.0;
+        }
+    } else {
+        for (long long i = tid; i < ld; i += 256) sw[i] = w[i];
+        __syncthreads();
+    }
+
+    for (long long rbase = ((long long)blockIdx.x * 4 + wave) * rows_per_step; rbase < n; rbase += stride) {
+        double acc[U];
+        const pkt_t* rowp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            long long r = rbase + (long long)u * RPW + rsub;
+            if (r >= n) r = n - 1;  // clamp: read a valid row, result discarded below
+            rowp[u] = reinterpret_cast<const pkt_t*>(D + r * ld);
+            acc[u] = 0.0;
+        }
+        if (P > 0) {
+            pkt_t buf[U][P > 0 ? P : 1];
+#pragma unroll
+            for (int p = 0; p < (P > 0 ? P : 1); ++p) {
+                long long pk = sub + (long long)p * LPR;
+                if (pk >= PK) pk = PK - 1;  // tail lanes re-read the last packet with w == 0
+#pragma unroll
+                for (int u = 0; u < U; ++u) buf[u][p] = rowp[u][pk];
+            }
+#pragma unroll
+            for (int p = 0; p < (P > 0 ? P : 1); ++p)
+#pragma unroll
+                for (int u = 0; u < U; ++u) Pkt<T>::fma(buf[u][p], wr[p], acc[u]);
+        } else {
+            for (long long pk = sub; pk < PK; pk += LPR) {
+                const double* wp = sw + pk * E;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    pkt_t x = rowp[u][pk];
+                    Pkt<T>::fma(x, wp, acc[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int off = LPR / 2; off > 0; off >>= 1) acc[u] += shfl_xor_d(acc[u], off);
+            long long r = rbase + (long long)u * RPW + rsub;
+            if (sub == 0 && r < n) v[r] = acc[u];
+        }
+    }
+}
+
+template <typename T, int LPR>
+int gemv_dispatch(const T* D, long long n, long long ld, const double* w, double* v, int num_cu, hipStream_t s) {
+    constexpr int E = Pkt<T>::E;
+    const long long PK = ld / E;
+    const long long passes = (PK + LPR - 1) / LPR;
+    int grid = num_cu * 8;
+    const long long rows_per_block = 4LL * (64 / LPR) * 2;
+    long long need = (n + rows_per_block - 1) / rows_per_block;
+    if (need < grid) grid = (int)(need > 0 ? need : 1);
+    if constexpr (LPR < 64) {
+        // a row fits one pass of its lane group
+        hipLaunchKernelGGL((k_gemv<T, LPR, 1, 4>), dim3(grid), dim3(256), 0, s, D, n, ld, w, v);
+    } else {
+        if (passes == 1)
+            hipLaunchKernelGGL((k_gemv<T, LPR, 1, 4>), dim3(grid), dim3(256), 0, s, D, n, ld, w, v);
+        else if (passes == 2)
+            hipLaunchKernelGGL((k_gemv<T, LPR, 2, 4>), dim3(grid), dim3(256), 0, s, D, n, ld, w, v);
+        else if (passes <= 4)
+            hipLaunchKernelGGL((k_gemv<T, LPR, 4, 2>), dim3(grid), dim3(256), 0, s, D, n, ld, w, v);
+        else if (passes <= 8)
+            hipLaunchKernelGGL((k_gemv<T, LPR, 8, 1>), dim3(grid), dim3(256), 0, s, D, n, ld, w, v);
+        else {
+            size_t lds = (size_t)ld * sizeof(double);
+            if (lds > 150 * 1024) {
+                rbl_set_error("gemv: d too large for the LDS-staged path (ld=%lld)", ld);
+                return RBL_ERR_INVALID;
+            }
+            if (lds > 64 * 1024) {
+                RBL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemv<T, LPR, 0, 4>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
+            hipLaunchKernelGGL((k_gemv<T, LPR, 0, 4>), dim3(grid), dim3(256), lds, s, D, n, ld, w, v);
+        }
+    }
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+template <typename T>
+int gemv_T(const T* D, long long n, long long ld, const double* w, double* v, int num_cu, hipStream_t s) {
+    const long long PK = ld / Pkt<T>::E;
+    if (PK > 32) return gemv_dispatch<T, 64>(D, n, ld, w, v, num_cu, s);
+    if (PK > 16) return gemv_dispatch<T, 32>(D, n, ld, w, v, num_cu, s);
+    if (PK > 8) return gemv_dispatch<T, 16>(D, n, ld, w, v, num_cu, s);
+    if (PK > 4) return gemv_dispatch<T, 8>(D, n, ld, w, v, num_cu, s);
+    if (PK > 2) return gemv_dispatch<T, 4>(D, n, ld, w, v, num_cu, s);
+    if (PK > 1) return gemv_dispatch<T, 2>(D, n, ld, w, v, num_cu, s);
+    return gemv_dispatch<T, 1>(D, n, ld, w, v, num_cu, s);
+}
+
+// ---------------------------------------------------------------------------- q = D^T c
+// TPR threads share one row (power of two <= 256); the block covers 256/TPR rows per
+// step with U steps in flight; thread `sub` owns packets sub + j*TPR (j < PJ) of the
+// column tile blockIdx.y, so partial column sums stay in registers for the block's
+// whole row range.  One slab row per block, reduced by k_colreduce (deterministic).
+// SQ = true accumulates c*x^2 as well (column statistics).
+template <typename T, int TPR, int PJ, int U, bool SQ>
+__global__ __launch_bounds__(256) void k_gemvt(const T* __restrict__ D, long long n, long long ld,
+                                                  const double* __restrict__ c, double* __restrict__ slab,
+                                                  double* __restrict__ slab2) {
+    typedef typename Pkt<T>::type pkt_t;
+    constexpr int E = Pkt<T>::E;
+    constexpr int RPB = 256 / TPR;
+    const int tid = threadIdx.x;
+    const int sub = tid % TPR, rsub = tid / TPR;
+    const long long PK = ld / E;
+    const long long col0 = (long long)blockIdx.y * TPR * PJ;  // first packet of this column tile
+    // contiguous row range of this block
+    const long long rows_per_block = (n + gridDim.x - 1) / gridDim.x;
+    const long long r_begin = (long long)blockIdx.x * rows_per_block;
+    long long r_end = r_begin + rows_per_block;
+    if (r_end > n) r_end = n;
+
+    double acc[PJ][E];
+    double acc2[SQ ? PJ : 1][E];
+#pragma unroll
+    for (int j = 0; j < PJ; ++j)
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            acc[j][k] = 0.0;
+            if (SQ) acc2[j][k] = 0.0;
+        }
+    long long pk[PJ];
+    bool pkv[PJ];
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+        pk[j] = col0 + sub + (long long)j * TPR;
+        pkv[j] = pk[j] < PK;
+        if (!pkv[j]) pk[j] = PK - 1;
+    }
+
+    for (long long rbase = r_begin; rbase < r_end; rbase += (long long)RPB * U) {
+        pkt_t buf[U][PJ];
+        double cv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            long long r = rbase + (long long)u * RPB + rsub;
+            bool ok = r < r_end;
+            if (!ok) r = r_end - 1;
+            cv[u] = ok ? (c ? c[r] : 1.0) : 0.0;
+            const pkt_t* rp = reinterpret_cast<const pkt_t*>(D + r * ld);
+#pragma unroll
+            for (int j = 0; j < PJ; ++j) buf[u][j] = rp[pk[j]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < PJ; ++j) Pkt<T>::axpy(buf[u][j], cv[u], acc[j]);
+        if (SQ) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < PJ; ++j) {
+                    if constexpr (E == 4) {
+                        double a = (double)buf[u][j].x, b = (double)buf[u][j].y, cc = (double)buf[u][j].z,
+                               dd = (double)buf[u][j].w;
+                        acc2[j][0] = __builtin_fma(a * a, cv[u], acc2[j][0]);
+                        acc2[j][1] = __builtin_fma(b * b, cv[u], acc2[j][1]);
+                        acc2[j][2] = __builtin_fma(cc * cc, cv[u], acc2[j][2]);
+                        acc2[j][3] = __builtin_fma(dd * dd, cv[u], acc2[j][3]);
+                    } else {
+                        double a = (double)buf[u][j].x, b = (double)buf[u][j].y;
+                        acc2[j][0] = __builtin_fma(a * a, cv[u], acc2[j][0]);
+                        acc2[j][1] = __builtin_fma(b * b, cv[u], acc2[j][1]);
+                    }
+                }
+        }
+    }
+
+    // fold the RPB row groups of the block (only when a row is narrower than the block)
+    if (RPB > 1) {
+        __shared__ double red[256 * 4];
+        for (int pass = 0; pass < (SQ ? 2 : 1); ++pass) {
+#pragma unroll
+            for (int j = 0; j < PJ; ++j) {
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < E; ++k) red[tid * E + k] = pass ? acc2[SQ ? j : 0][k] : acc[j][k];
+                __syncthreads();
+                if (rsub == 0) {
+#pragma unroll
+                    for (int k = 0; k < E; ++k) {
+                        double sacc = 0.0;
+                        for (int g = 0; g < RPB; ++g) sacc += red[(g * TPR + sub) * E + k];
+                        if (pass) acc2[SQ ? j : 0][k] = sacc; else acc[j][k] = sacc;
+                    }
+                }
+            }
+        }
+    }
+    if (rsub == 0) {
+#pragma unroll
+        for (int j = 0; j < PJ; ++j)
+            if (pkv[j]) {
+#pragma unroll
+                for (int k = 0; k < E; ++k) {
+                    slab[(long long)blockIdx.x * ld + pk[j] * E + k] = acc[j][k];
+                    if (SQ) slab2[(long long)blockIdx.x * ld + pk[j] * E + k] = acc2[j][k];
+                }
+            }
+    }
+}
+
+// q[j] = sum_b slab[b][j]: 64 columns x 16 row groups per block, fixed summation order.
+__global__ __launch_bounds__(1024) void k_colreduce(const double* __restrict__ slab, int nb, long long ld,
+                                                      double* __restrict__ q) {
+    __shared__ double red[16][64];
+    const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long long col = (long long)blockIdx.x * 64 + cx;
+    double acc = 0.0;
+    if (col < ld)
+        for (int b = g; b < nb; b += 16) acc += slab[(long long)b * ld + col];
+    red[g][cx] = acc;
+    __syncthreads();
+    if (g == 0 && col < ld) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sacc += red[k][cx];
+        q[col] = sacc;
+    }
+}
+
+constexpr int GEMVT_BLOCKS_PER_CU = 4;
+
+template <typename T, int TPR, bool SQ>
+int gemvt_dispatch(const T* D, long long n, long long ld, const double* c, double* slab, double* slab2,
+                   int nblocks, hipStream_t s) {
+    constexpr int E = Pkt<T>::E;
+    const long long PK = ld / E;
+    long long pj = (PK + TPR - 1) / TPR;
+    int ytiles = 1;
+    if (pj > 8) {
+        ytiles = (int)((pj + 7) / 8);
+        pj = 8;
+    }
+    dim3 grid(nblocks, ytiles);
+    if constexpr (TPR < 256) {
+        hipLaunchKernelGGL((k_gemvt<T, TPR, 1, 8, SQ>), grid, dim3(256), 0, s, D, n, ld, c, slab, slab2);
+    } else {
+        if (pj == 1)
+            hipLaunchKernelGGL((k_gemvt<T, TPR, 1, 8, SQ>), grid, dim3(256), 0, s, D, n, ld, c, slab, slab2);
+        else if (pj == 2)
+            hipLaunchKernelGGL((k_gemvt<T, TPR, 2, 4, SQ>), grid, dim3(256), 0, s, D, n, ld, c, slab, slab2);
+        else if (pj <= 4)
+            hipLaunchKernelGGL((k_gemvt<T, TPR, 4, 2, SQ>), grid, dim3(256), 0, s, D, n, ld, c, slab, slab2);
+        else
+            hipLaunchKernelGGL((k_gemvt<T, TPR, 8, 1, SQ>), grid, dim3(256), 0, s, D, n, ld, c, slab, slab2);
+    }
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+template <typename T, bool SQ>
+int gemvt_T(const T* D, long long n, long long ld, const double* c, double* slab, double* slab2, int nblocks,
+            hipStream_t s) {
+    const long long PK = ld / Pkt<T>::E;
+    if (PK > 128) return gemvt_dispatch<T, 256, SQ>(D, n, ld, c, slab, slab2, nblocks, s);
+    if (PK > 64) return gemvt_dispatch<T, 128, SQ>(D, n, ld, c, slab, slab2, nblocks, s);
+    if (PK > 32) return gemvt_dispatch<T, 64, SQ>(D, n, ld, c, slab, slab2, nblocks, s);
+    if (PK > 16) return gemvt_dispatch<T, 32, SQ>(D, n, ld, c, slab, slab2, nblocks, s);
+    if (PK > 8) return gemvt_dispatch<T, 16, SQ>(D, n, ld, c, slab, slab2, nblocks, s);
+    if (PK > 4) return gemvt_dispatch<T, 8, SQ>(D, n, ld, c, slab, slab2, nblocks, s);
+    if (PK > 2) return gemvt_dispatch<T, 4, SQ>(D, n, ld, c, slab, slab2, nblocks, s);
+    if (PK > 1) return gemvt_dispatch<T, 2, SQ>(D, n, ld, c, slab, slab2, nblocks, s);
+    return gemvt_dispatch<T, 1, SQ>(D, n, ld, c, slab, slab2, nblocks, s);
+}
+
+int gemvt_blocks(int num_cu, long long n) {
+    long long nb = (long long)num_cu * GEMVT_BLOCKS_PER_CU;
+    long long cap = (n + 63) / 64;  // at least 64 rows per block
+    if (cap < 1) cap = 1;
+    if (nb > cap) nb = cap;
+    return (int)nb;
+}
+
+// ------------------------------------------------------------------- forming / reading D
+template <typename T>
+__global__ void k_form_D(T* __restrict__ D, long long ld, long long row0, const double* __restrict__ X,
+                         long long ldx, const double* __restrict__ y, long long rows, long long d) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ld) return;
+    long long r = i / ld, j = i - r * ld;
+    double val = (j < d) ? -y[r] * X[r * ldx + j] : 0.0;  // algorithms.py:23  D = -y * X
+    D[(row0 + r) * ld + j] = (T)val;
+}
+
+template <typename T>
+__global__ void k_D_to_f64(const T* __restrict__ D, long long ld, long long n, long long d,
+                           double* __restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * d) return;
+    long long r = i / d, j = i - r * d;
+    out[i] = (double)D[r * ld + j];
+}
+
+template <typename T>
+__global__ void k_standardize_negy(T* __restrict__ D, long long n, long long ld, long long d,
+                                   const double* __restrict__ mean, const double* __restrict__ inv_std,
+                                   const signed char* __restrict__ ysign) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * ld) return;
+    long long r = i / ld, j = i - r * ld;
+    if (j >= d) return;
+    double x = ((double)D[i] - mean[j]) * inv_std[j];
+    D[i] = (T)(-(double)ysign[r] * x);
+}
+
+}  // namespace
+
+int gemvt_slab_rows(int num_cu) { return num_cu * GEMVT_BLOCKS_PER_CU; }
+
+int launch_gemv(int storage, const void* D, int64_t n, int64_t ld, const double* w, double* v, int num_cu,
+                hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    if (storage == RBL_STORE_F32) return gemv_T<float>((const float*)D, n, ld, w, v, num_cu, s);
+    return gemv_T<double>((const double*)D, n, ld, w, v, num_cu, s);
+}
+
+int launch_gemvt(int storage, const void* D, int64_t n, int64_t ld, const double* c, double* slab, double* q,
+                 int num_cu, hipStream_t s) {
+    if (n <= 0) {
+        RBL_HIP(hipMemsetAsync(q, 0, sizeof(double) * ld, s));
+        return RBL_OK;
+    }
+    int nb = gemvt_blocks(num_cu, n);
+    if (storage == RBL_STORE_F32)
+        RBL_TRY((gemvt_T<float, false>((const float*)D, n, ld, c, slab, nullptr, nb, s)));
+    else
+        RBL_TRY((gemvt_T<double, false>((const double*)D, n, ld, c, slab, nullptr, nb, s)));
+    hipLaunchKernelGGL(k_colreduce, dim3((unsigned)((ld + 63) / 64)), dim3(1024), 0, s, slab, nb, (long long)ld, q);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_colstats(int storage, const void* D, int64_t n, int64_t ld, double* slab, double* sum,
+                    double* sumsq, int num_cu, hipStream_t s) {
+    int nb = gemvt_blocks(num_cu, n);
+    double* slab2 = slab + (size_t)gemvt_slab_rows(num_cu) * ld;
+    if (storage == RBL_STORE_F32)
+        RBL_TRY((gemvt_T<float, true>((const float*)D, n, ld, nullptr, slab, slab2, nb, s)));
+    else
+        RBL_TRY((gemvt_T<double, true>((const double*)D, n, ld, nullptr, slab, slab2, nb, s)));
+    hipLaunchKernelGGL(k_colreduce, dim3((unsigned)((ld + 63) / 64)), dim3(1024), 0, s, slab, nb, (long long)ld, sum);
+    hipLaunchKernelGGL(k_colreduce, dim3((unsigned)((ld + 63) / 64)), dim3(1024), 0, s, slab2, nb, (long long)ld, sumsq);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_form_D(int storage, void* D, int64_t ld, int64_t row0, const double* Xdev, int64_t ldx,
+                  const double* ydev, int64_t rows, int64_t d, hipStream_t s) {
+    long long total = rows * ld;
+    if (total <= 0) return RBL_OK;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (storage == RBL_STORE_F32)
+        hipLaunchKernelGGL(k_form_D<float>, dim3(grid), dim3(256), 0, s, (float*)D, (long long)ld, (long long)row0,
+                           Xdev, (long long)ldx, ydev, (long long)rows, (long long)d);
+    else
+        hipLaunchKernelGGL(k_form_D<double>, dim3(grid), dim3(256), 0, s, (double*)D, (long long)ld,
+                           (long long)row0, Xdev, (long long)ldx, ydev, (long long)rows, (long long)d);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_D_to_f64(int storage, const void* D, int64_t ld, int64_t n, int64_t d, double* out, hipStream_t s) {
+    long long total = n * d;
+    if (total <= 0) return RBL_OK;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (storage == RBL_STORE_F32)
+        hipLaunchKernelGGL(k_D_to_f64<float>, dim3(grid), dim3(256), 0, s, (const float*)D, (long long)ld,
+                           (long long)n, (long long)d, out);
+    else
+        hipLaunchKernelGGL(k_D_to_f64<double>, dim3(grid), dim3(256), 0, s, (const double*)D, (long long)ld,
+                           (long long)n, (long long)d, out);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_standardize_negy(int storage, void* D, int64_t n, int64_t ld, int64_t d, const double* mean,
+                            const double* inv_std, const signed char* ysign, hipStream_t s) {
+    long long total = n * ld;
+    if (total <= 0) return RBL_OK;
+    long long nblk = (total + 255) / 256;
+    if (nblk > 0x7fffffffLL) {
+        rbl_set_error("standardize: grid too large");
+        return RBL_ERR_INVALID;
+    }
+    if (storage == RBL_STORE_F32)
+        hipLaunchKernelGGL(k_standardize_negy<float>, dim3((unsigned)nblk), dim3(256), 0, s, (float*)D, (long long)n,
+                           (long long)ld, (long long)d, mean, inv_std, ysign);
+    else
+        hipLaunchKernelGGL(k_standardize_negy<double>, dim3((unsigned)nblk), dim3(256), 0, s, (double*)D,
+                           (long long)n, (long long)ld, (long long)d, mean, inv_std, ysign);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}

@@ -1,0 +1,350 @@
+// wstep.hip - the w-sub-problem in Gram space (d-space), fp64.
+//
+// The reference solves the w-step in n-space: backtracking FISTA with >= 3 sweeps of D per
+// inner iteration (src/util/fast_lasso.py:22-69, called from src/optim/algorithms.py:190-202)
+// or SciPy L-BFGS-B with 2 sweeps per evaluation (src/util/w_LBFGS.py:31-62).  With
+// G = D^T D (algorithms.py:24) and q = D^T (z + lambda/rho) the same convex problems are
+//   lasso:        min 1/2 w'Gw - q'w + reg/(2 rho) ||w||_1
+//   ridge:        (rho G + reg I) w = rho q
+//   smoothed l1:  min rho/2 w'Gw - rho q'w + sum_j h_t(w_j)      (w_LBFGS.py:11-28)
+// and cost one d x d mat-vec per inner iteration (G stays in L2 / Infinity Cache).
+// Lasso and smoothed-l1: FISTA with fixed step 1/L and gradient restart; ridge: CG.
+// Each inner iteration = k_symv (all CUs) + one single-block update kernel that owns all
+// reductions (fixed order, deterministic) and the convergence flag; no host round trip
+// inside a batch of iterations.
+#include "rbl_internal.h"
+#include "device_math.h"
+
+namespace {
+
+// y = alpha * G x + beta * x ; G is ld x ld row-major, one row per wave
+__global__ __launch_bounds__(256) void k_symv(const double* __restrict__ G, long long ld,
+                                               const double* __restrict__ x, double* __restrict__ y, double alpha,
+                                               double beta, const int* __restrict__ done) {
+    if (done && *done) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < ld; row += (long long)gridDim.x * 4) {
+        const double2* g2 = reinterpret_cast<const double2*>(G + row * ld);
+        const double2* x2 = reinterpret_cast<const double2*>(x);
+        double acc = 0.0;
+        for (long long j = lane; j < ld / 2; j += 64) {
+            double2 a = g2[j], b = x2[j];
+            acc = __builtin_fma(a.x, b.x, acc);
+            acc = __builtin_fma(a.y, b.y, acc);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) y[row] = alpha * acc + beta * x[row];
+    }
+}
+
+constexpr int UPD_THREADS = 1024;
+constexpr int UPD_PER = 16;  // d <= 16384 in the single-block update kernels
+
+struct FistaParams {
+    int mode;      // 0 lasso (soft threshold), 1 smoothed l1 (Huber prox)
+    double L;      // Lipschitz constant of the quadratic (lambda_max(G) * safety)
+    double kappa;  // lasso: reg / (2 rho)
+    double rho, reg, t;
+    double tol;
+};
+
+__device__ inline double soft_thr(double b, double k) {
+    // src/util/fast_lasso.py:15-19
+    double a = fabs(b) - k;
+    return a > 0.0 ? copysign(a, b) : 0.0;
+}
+__device__ inline double huber_prox(double b, double Ls, double reg, double t) {
+    // argmin_u Ls/2 (u-b)^2 + h_t(u), h_t from src/util/w_LBFGS.py:11-19
+    double uin = b * Ls / (Ls + reg / (2.0 * t));
+    return (fabs(uin) <= t) ? uin : b - copysign(reg / (2.0 * Ls), b);
+}
+
+// scal[0] = FISTA t_k ; flags[0] = done, flags[1] = iterations performed
+__global__ __launch_bounds__(UPD_THREADS) void k_fista_update(long long ld, const double* __restrict__ Gy,
+                                                               const double* __restrict__ q, double* __restrict__ w,
+                                                               double* __restrict__ yk, FistaParams P,
+                                                               double* __restrict__ scal, int* __restrict__ flags) {
+    if (flags[0]) return;
+    __shared__ double smem[3 * UPD_THREADS / 64];
+    double wn[UPD_PER], dw[UPD_PER];
+    double acc[1] = {0.0};  // restart test: sum (y - x)(x - w)
+    double mx_dw = 0.0, mx_w = 0.0;
+#pragma unroll
+    for (int k = 0; k < UPD_PER; ++k) {
+        const long long j = (long long)k * UPD_THREADS + threadIdx.x;
+        wn[k] = 0.0;
+        dw[k] = 0.0;
+        if (j < ld) {
+            const double y = yk[j];
+            const double b = y - (Gy[j] - q[j]) / P.L;
+            const double x = (P.mode == 0) ? soft_thr(b, P.kappa / P.L) : huber_prox(b, P.rho * P.L, P.reg, P.t);
+            const double dd = x - w[j];
+            wn[k] = x;
+            dw[k] = dd;
+            acc[0] += (y - x) * dd;
+            mx_dw = fmax(mx_dw, fabs(dd));
+            mx_w = fmax(mx_w, fabs(x));
+        }
+    }
+    rbl::block_sum<1, UPD_THREADS>(acc, smem);
+    // block max of the two magnitudes
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mx_dw = fmax(mx_dw, __shfl_xor(mx_dw, off, 64));
+        mx_w = fmax(mx_w, __shfl_xor(mx_w, off, 64));
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        smem[(threadIdx.x >> 6) * 2 + 0] = mx_dw;
+        smem[(threadIdx.x >> 6) * 2 + 1] = mx_w;
+    }
+    __syncthreads();
+    for (int wv = 0; wv < UPD_THREADS / 64; ++wv) {
+        mx_dw = fmax(mx_dw, smem[wv * 2 + 0]);
+        mx_w = fmax(mx_w, smem[wv * 2 + 1]);
+    }
+    const double t = scal[0];
+    const bool restart = acc[0] > 0.0;  // O'Donoghue-Candes gradient restart
+    const double tn = restart ? 1.0 : 0.5 * (1.0 + sqrt(1.0 + 4.0 * t * t));
+    const double coef = restart ? 0.0 : (t - 1.0) / tn;
+#pragma unroll
+    for (int k = 0; k < UPD_PER; ++k) {
+        const long long j = (long long)k * UPD_THREADS + threadIdx.x;
+        if (j < ld) {
+            w[j] = wn[k];
+            yk[j] = wn[k] + coef * dw[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scal[0] = tn;
+        flags[1] += 1;
+        if (mx_dw <= P.tol * fmax(1.0, mx_w)) flags[0] = 1;
+    }
+}
+
+// CG on A = rho G + reg I.  scal[1] = r'r, scal[2] = stop threshold on r'r
+__global__ __launch_bounds__(UPD_THREADS) void k_cg_init(long long ld, const double* __restrict__ Aw,
+                                                          const double* __restrict__ q, double rho,
+                                                          double* __restrict__ r, double* __restrict__ p, double tol,
+                                                          double* __restrict__ scal, int* __restrict__ flags) {
+    __shared__ double smem[2 * UPD_THREADS / 64];
+    double acc[2] = {0.0, 0.0};
+    for (long long j = threadIdx.x; j < ld; j += UPD_THREADS) {
+        const double b = rho * q[j];
+        const double rr = b - Aw[j];
+        r[j] = rr;
+        p[j] = rr;
+        acc[0] += rr * rr;
+        acc[1] += b * b;
+    }
+    rbl::block_sum<2, UPD_THREADS>(acc, smem);
+    if (threadIdx.x == 0) {
+        scal[1] = acc[0];
+        scal[2] = tol * tol * acc[1];
+        flags[0] = (acc[0] <= scal[2]) ? 1 : 0;
+        flags[1] = 0;
+    }
+}
+
+__global__ __launch_bounds__(UPD_THREADS) void k_cg_update(long long ld, const double* __restrict__ Ap,
+                                                            double* __restrict__ w, double* __restrict__ r,
+                                                            double* __restrict__ p, double* __restrict__ scal,
+                                                            int* __restrict__ flags) {
+    if (flags[0]) return;
+    __shared__ double smem[UPD_THREADS / 64];
+    double pk[UPD_PER], rk[UPD_PER];
+    double acc[1] = {0.0};
+#pragma unroll
+    for (int k = 0; k < UPD_PER; ++k) {
+        const long long j = (long long)k * UPD_THREADS + threadIdx.x;
+        pk[k] = (j < ld) ? p[j] : 0.0;
+        acc[0] += (j < ld) ? pk[k] * Ap[j] : 0.0;
+    }
+    rbl::block_sum<1, UPD_THREADS>(acc, smem);
+    const double rr = scal[1];
+    const double alpha = (acc[0] > 0.0) ? rr / acc[0] : 0.0;
+    double acc2[1] = {0.0};
+#pragma unroll
+    for (int k = 0; k < UPD_PER; ++k) {
+        const long long j = (long long)k * UPD_THREADS + threadIdx.x;
+        rk[k] = 0.0;
+        if (j < ld) {
+            w[j] += alpha * pk[k];
+            rk[k] = r[j] - alpha * Ap[j];
+            acc2[0] += rk[k] * rk[k];
+        }
+    }
+    rbl::block_sum<1, UPD_THREADS>(acc2, smem);
+    const double beta = (rr > 0.0) ? acc2[0] / rr : 0.0;
+#pragma unroll
+    for (int k = 0; k < UPD_PER; ++k) {
+        const long long j = (long long)k * UPD_THREADS + threadIdx.x;
+        if (j < ld) {
+            r[j] = rk[k];
+            p[j] = rk[k] + beta * pk[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scal[1] = acc2[0];
+        flags[1] += 1;
+        if (acc2[0] <= scal[2] || alpha == 0.0) flags[0] = 1;
+    }
+}
+
+// x <- y / ||y|| ; scal[3] = ||y||
+__global__ __launch_bounds__(UPD_THREADS) void k_normalize(long long ld, const double* __restrict__ y,
+                                                            double* __restrict__ x, double* __restrict__ scal) {
+    __shared__ double smem[UPD_THREADS / 64];
+    double acc[1] = {0.0};
+    for (long long j = threadIdx.x; j < ld; j += UPD_THREADS) acc[0] += y[j] * y[j];
+    rbl::block_sum<1, UPD_THREADS>(acc, smem);
+    const double nrm = sqrt(acc[0]);
+    const double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
+    for (long long j = threadIdx.x; j < ld; j += UPD_THREADS) x[j] = y[j] * inv;
+    if (threadIdx.x == 0) scal[3] = nrm;
+}
+
+__global__ void k_power_init(long long ld, long long d, double* __restrict__ x) {
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < ld; j += (long long)gridDim.x * blockDim.x) {
+        // fixed pseudo-random start vector (never orthogonal to the top eigenvector in practice)
+        unsigned long long h = (unsigned long long)(j + 1) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+        x[j] = (j < d) ? 0.5 + (double)(h & 0xffff) / 65536.0 : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(UPD_THREADS) void k_diffnorm2(long long d, const double* __restrict__ a,
+                                                            const double* __restrict__ b, double* __restrict__ out) {
+    __shared__ double smem[UPD_THREADS / 64];
+    double acc[1] = {0.0};
+    for (long long j = threadIdx.x; j < d; j += UPD_THREADS) {
+        const double t = a[j] - b[j];
+        acc[0] += t * t;
+    }
+    rbl::block_sum<1, UPD_THREADS>(acc, smem);
+    if (threadIdx.x == 0) out[0] = acc[0];
+}
+
+__global__ __launch_bounds__(UPD_THREADS) void k_reg_terms(long long d, const double* __restrict__ w,
+                                                            double* __restrict__ out) {
+    __shared__ double smem[2 * UPD_THREADS / 64];
+    double acc[2] = {0.0, 0.0};
+    for (long long j = threadIdx.x; j < d; j += UPD_THREADS) {
+        acc[0] += w[j] * w[j];
+        acc[1] += fabs(w[j]);
+    }
+    rbl::block_sum<2, UPD_THREADS>(acc, smem);
+    if (threadIdx.x == 0) {
+        out[0] = acc[0];  // objective.py:83-84  sum w^2
+        out[1] = acc[1];  // objective.py:85-86  ||w||_1
+    }
+}
+
+__global__ void k_soft_threshold(long long d, double* __restrict__ w, double t) {
+    // smoothADMMmethod's final step, src/optim/algorithms.py:258
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < d; j += (long long)gridDim.x * blockDim.x) {
+        const double a = fabs(w[j]) - t;
+        w[j] = a > 0.0 ? copysign(a, w[j]) : 0.0;
+    }
+}
+
+inline unsigned symv_grid(long long ld) {
+    long long g = (ld + 3) / 4;
+    if (g > 4096) g = 4096;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+int launch_power_iteration(const double* G, int64_t ld, double* x, double* y, double* scal, int iters,
+                           double* lambda_host, hipStream_t s) {
+    hipLaunchKernelGGL(k_power_init, dim3(64), dim3(256), 0, s, (long long)ld, (long long)ld, x);
+    hipLaunchKernelGGL(k_normalize, dim3(1), dim3(UPD_THREADS), 0, s, (long long)ld, x, x, scal);
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(k_symv, dim3(symv_grid(ld)), dim3(256), 0, s, G, (long long)ld, x, y, 1.0, 0.0,
+                           (const int*)nullptr);
+        hipLaunchKernelGGL(k_normalize, dim3(1), dim3(UPD_THREADS), 0, s, (long long)ld, y, x, scal);
+    }
+    RBL_HIP(hipGetLastError());
+    RBL_HIP(hipMemcpyAsync(lambda_host, scal + 3, sizeof(double), hipMemcpyDeviceToHost, s));
+    RBL_HIP(hipStreamSynchronize(s));
+    return RBL_OK;
+}
+
+int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rho, double reg, double smooth_t,
+              double L, double tol, int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s) {
+    if (ld > (long long)UPD_THREADS * UPD_PER) {
+        rbl_set_error("w-step: d=%lld exceeds the single-block update limit %d", (long long)ld, UPD_THREADS * UPD_PER);
+        return RBL_ERR_INVALID;
+    }
+    const unsigned sg = symv_grid(ld);
+    int hflags[2] = {0, 0};
+    constexpr int BATCH = 8;
+    if (wstep == RBL_WSTEP_L2) {
+        // (rho G + reg I) w = rho q
+        hipLaunchKernelGGL(k_symv, dim3(sg), dim3(256), 0, s, G, (long long)ld, w, ws.Gy, rho, reg, (const int*)nullptr);
+        hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(UPD_THREADS), 0, s, (long long)ld, ws.Gy, q, rho, ws.r, ws.p, tol,
+                           ws.scal, ws.flags);
+        int done_iters = 0;
+        while (done_iters < max_inner) {
+            for (int b = 0; b < BATCH; ++b) {
+                hipLaunchKernelGGL(k_symv, dim3(sg), dim3(256), 0, s, G, (long long)ld, ws.p, ws.Gy, rho, reg, ws.flags);
+                hipLaunchKernelGGL(k_cg_update, dim3(1), dim3(UPD_THREADS), 0, s, (long long)ld, ws.Gy, w, ws.r, ws.p,
+                                   ws.scal, ws.flags);
+            }
+            done_iters += BATCH;
+            RBL_HIP(hipMemcpyAsync(hflags, ws.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+            RBL_HIP(hipStreamSynchronize(s));
+            if (hflags[0]) break;
+        }
+    } else {
+        FistaParams P;
+        P.mode = (wstep == RBL_WSTEP_L1) ? 0 : 1;
+        P.L = L;
+        P.kappa = reg / (2.0 * rho);
+        P.rho = rho;
+        P.reg = reg;
+        P.t = smooth_t;
+        P.tol = tol;
+        const double one = 1.0;
+        RBL_HIP(hipMemcpyAsync(ws.scal, &one, sizeof(double), hipMemcpyHostToDevice, s));
+        RBL_HIP(hipMemsetAsync(ws.flags, 0, 2 * sizeof(int), s));
+        RBL_HIP(hipMemcpyAsync(ws.yk, w, sizeof(double) * ld, hipMemcpyDeviceToDevice, s));
+        int done_iters = 0;
+        while (done_iters < max_inner) {
+            for (int b = 0; b < BATCH; ++b) {
+                hipLaunchKernelGGL(k_symv, dim3(sg), dim3(256), 0, s, G, (long long)ld, ws.yk, ws.Gy, 1.0, 0.0, ws.flags);
+                hipLaunchKernelGGL(k_fista_update, dim3(1), dim3(UPD_THREADS), 0, s, (long long)ld, ws.Gy, q, w, ws.yk,
+                                   P, ws.scal, ws.flags);
+            }
+            done_iters += BATCH;
+            RBL_HIP(hipMemcpyAsync(hflags, ws.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+            RBL_HIP(hipStreamSynchronize(s));
+            if (hflags[0]) break;
+        }
+    }
+    RBL_HIP(hipGetLastError());
+    if (iters_host) *iters_host = hflags[1];
+    return RBL_OK;
+}
+
+int launch_diffnorm2(int64_t d, const double* a, const double* b, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_diffnorm2, dim3(1), dim3(UPD_THREADS), 0, s, (long long)d, a, b, out);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_reg_terms(int64_t d, const double* w, double* out2, hipStream_t s) {
+    hipLaunchKernelGGL(k_reg_terms, dim3(1), dim3(UPD_THREADS), 0, s, (long long)d, w, out2);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_soft_threshold(int64_t d, double* w, double t, hipStream_t s) {
+    hipLaunchKernelGGL(k_soft_threshold, dim3(16), dim3(256), 0, s, (long long)d, w, t);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}

@@ -1,0 +1,205 @@
+/* rbl.h - C ABI of librbl.so: the ADMM inner iteration for rank-based loss
+ * minimisation on AMD Instinct MI355X (gfx950), hand-written HIP.
+ *
+ * This is the drop-in boundary for the hot path of RufengXiao/ADMM-for-rank-based-loss
+ * (reference paths below are relative to that repository).  The reference has no
+ * FFI layer - its boundary is the Python class API of src/optim/algorithms.py - so
+ * every entry point names the reference interface it stands behind; the Python
+ * mirror of that class API (admm-for-rank-based-loss_amd/src/optim/algorithms.py)
+ * binds these symbols with ctypes (see INTEGRATION.md for the stub).
+ *
+ * Conventions: plain pointers and sizes only; every function returns an int status
+ * (0 = ok, <0 = error, message via rbl_last_error()); no exceptions cross the
+ * boundary; the library owns all device memory; the caller owns all host buffers;
+ * no callbacks.  One solver handle per host thread.  Host arrays are row-major
+ * float64 unless stated.  There is NO CPU fallback: every compute entry point
+ * fails with RBL_ERR_NO_DEVICE when no gfx950 device is present.
+ */
+#ifndef RBL_H
+#define RBL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBL_VERSION 100
+
+/* status codes */
+enum {
+    RBL_OK = 0,
+    RBL_ERR_INVALID = -1,    /* bad argument / bad configuration (Python side raises ValueError) */
+    RBL_ERR_NO_DEVICE = -2,  /* no HIP device: the product path has no CPU fallback */
+    RBL_ERR_HIP = -3,        /* a HIP runtime call failed */
+    RBL_ERR_STATE = -4,      /* call order violated (e.g. step before set_data) */
+    RBL_ERR_NOMEM = -5
+};
+
+/* loss: src/optim/objective.py:27-37 (get_loss); the ADMM z-step supports these two
+ * (src/util/individual_solver.py:112-123) */
+enum { RBL_LOSS_BCE = 0, RBL_LOSS_HINGE = 1 };
+
+/* weight_function: src/optim/objective.py:166-187 (get_weights) */
+enum {
+    RBL_W_ERM = 0, RBL_W_EXTREMILE = 1, RBL_W_SUPERQUANTILE = 2, RBL_W_ESRM = 3,
+    RBL_W_AORR = 4, RBL_W_AORR_DC = 5, RBL_W_EHRM = 6
+};
+
+/* w-step flavour: src/optim/algorithms.py:57-60,190-207 (ADMMmethod) and :238-246
+ * (smoothADMMmethod) */
+enum { RBL_WSTEP_L1 = 1, RBL_WSTEP_L2 = 2, RBL_WSTEP_SMOOTH_L1 = 3 };
+
+/* element type D = -y*X is stored in (accumulation is always float64) */
+enum { RBL_STORE_F32 = 0, RBL_STORE_F64 = 1 };
+
+/* Constructor arguments of Optimizer.__init__ (src/optim/algorithms.py:20-75). */
+typedef struct rbl_config {
+    int64_t n;              /* rows held by THIS process (its shard of the sample axis) */
+    int64_t d;              /* features */
+    int64_t n_total;        /* rows of the whole problem (== n on one GPU) */
+    int64_t row_offset;     /* global index of this shard's first row */
+    int32_t loss;           /* RBL_LOSS_* */
+    int32_t weight_function;/* RBL_W_* */
+    double  weight_args[2]; /* args list (objective.py:174-183); unused entries 0 */
+    int32_t n_weight_args;  /* 0 = args is None */
+    int32_t has_B;          /* B is not None (ehrm only, algorithms.py:64-68) */
+    double  B;
+    int32_t wstep;          /* RBL_WSTEP_* */
+    double  reg;            /* l1_reg or l2_reg (algorithms.py:30) */
+    double  smooth_t;       /* smoothADMMmethod t (algorithms.py:225,228) */
+    double  rho0;           /* <= 0: reference default by weight_function (algorithms.py:47-52) */
+    double  tol;            /* stop tolerance (algorithms.py:44,137) */
+    double  w_tol;          /* inner w-step tolerance; <= 0: library default 1e-13 */
+    int32_t max_iter;       /* algorithms.py:45 */
+    int32_t storage;        /* RBL_STORE_* */
+    int32_t device;         /* HIP device ordinal */
+    int32_t objective_only; /* 1: handle used only for rbl_objective (rankbasedObjective) */
+} rbl_config;
+
+/* Per-iteration report of Optimizer.main_loop (src/optim/algorithms.py:119-164). */
+typedef struct rbl_stats {
+    int64_t iter;            /* iterations completed */
+    double  primal;          /* ||z - D w||_2           (algorithms.py:135) */
+    double  dual;            /* ||w - w_prev||_2        (algorithms.py:136) */
+    double  rho;             /* rho used in this iteration */
+    double  rho_next;        /* rho after the schedule  (algorithms.py:154-157) */
+    double  objective;       /* F(w) after the iteration (objective.py:71-87); NaN if not computed */
+    int32_t converged;       /* both residuals < tol    (algorithms.py:137) */
+    int32_t inner_iters;     /* w-step inner iterations */
+    int32_t ehrm_branch;     /* 0 = a (z<=B), 1 = b (z>=B), -1 = n/a (PAV_cpt.py:222-226) */
+    int32_t pav_merges;      /* seam merges performed by the PAV tree, -1 = n/a */
+    float   ms_z, ms_q, ms_w, ms_v, ms_total;  /* device time of the phases, HIP events */
+} rbl_stats;
+
+typedef struct rbl_solver rbl_solver;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+int  rbl_version(void);
+const char* rbl_last_error(void);
+int  rbl_device_count(void);
+/* Optimizer.__init__ / rankbasedObjective.__init__ */
+int  rbl_create(const rbl_config* cfg, rbl_solver** out);
+int  rbl_destroy(rbl_solver* h);
+/* run the library's kernels on this hipStream_t (NULL = the handle's own stream) */
+int  rbl_set_stream(rbl_solver* h, void* hip_stream);
+
+/* ---- data: D = -y * X (algorithms.py:23), G = D^T D (algorithms.py:24) ---------- */
+/* X: n x d host rows with leading dimension ldx, y: n labels (+-1). */
+int  rbl_set_data(rbl_solver* h, const double* X, const double* y, int64_t ldx);
+/* Synthetic two-class data generated on the device (statistics of
+ * src/util/load_data.py:101-116), never materialised on the host. */
+int  rbl_generate_synthetic(rbl_solver* h, uint64_t seed, double class_sep, double flip_y);
+/* sharded form: raw local rows + local column sums (RBL_BUF_COLSTATS, to be summed over
+ * ranks), then standardise and scale by -y.  Same matrix for any sharding of the rows. */
+int  rbl_synth_local(rbl_solver* h, uint64_t seed, double class_sep, double flip_y);
+int  rbl_synth_finish(rbl_solver* h);
+/* labels of the generated rows (+-1), n doubles */
+int  rbl_get_labels(rbl_solver* h, double* y_out);
+/* Build G and the w-step constants.  For multi-GPU runs call rbl_gram_local(), sum
+ * the d*d buffer across ranks (rbl_buffer RBL_BUF_G) and then rbl_gram_finish(). */
+int  rbl_gram_local(rbl_solver* h);
+int  rbl_gram_finish(rbl_solver* h);
+int  rbl_get_D(rbl_solver* h, double* out /* n x d */);
+
+/* ---- state: w, z, lambda, rho (algorithms.py:32-52); NULL pointers are skipped ---- */
+int  rbl_get_state(rbl_solver* h, double* w, double* z, double* lam, double* rho, int64_t* iter, double* smooth_t);
+int  rbl_set_state(rbl_solver* h, const double* w, const double* z, const double* lam, const double* rho, const int64_t* iter, const double* smooth_t);
+int  rbl_get_sigma(rbl_solver* h, double* alphas, double* betas /* n_total each */);
+
+/* ---- the hot path ---------------------------------------------------------------- */
+/* One ADMM iteration = Optimizer.main_loop(i, ...) (algorithms.py:119-164).
+ * want_objective != 0 also evaluates F(w_{k+1}) from the cached D w (the `store`
+ * logging of algorithms.py:159-161). */
+int  rbl_step(rbl_solver* h, int want_objective, rbl_stats* out);
+/* ADMMmethod.main_loop / smoothADMMmethod.main_loop (algorithms.py:209-216, 248-260):
+ * up to max_iter steps, stops on convergence; history arrays (may be NULL) receive
+ * one entry per iteration, cap entries each. */
+int  rbl_solve(rbl_solver* h, int max_iter, int want_objective, rbl_stats* last,
+               double* hist_objective, double* hist_primal, double* hist_dual, double* hist_rho,
+               double* hist_time_s, int64_t cap);
+/* smoothADMMmethod's final soft-threshold of w by t (algorithms.py:257-258) */
+int  rbl_finalize_smooth(rbl_solver* h);
+/* rankbasedObjective.get_arrogate_loss(w) (objective.py:71-87); w: d host doubles */
+int  rbl_objective(rbl_solver* h, const double* w, int include_reg, double* out);
+
+/* ---- phase API (one process per GPU; the host does the collectives in between) ---- */
+/* A: m = D w - lambda/rho for the local rows (algorithms.py:89) -> RBL_BUF_M */
+int  rbl_phase_m(rbl_solver* h);
+/* B: z-step (algorithms.py:92-104).  m_all_dev: device pointer to the n_total gathered
+ * m values (rank order) or NULL when n == n_total or weight_function == erm. */
+int  rbl_phase_z(rbl_solver* h, const void* m_all_dev);
+/* C: local q = D^T (z + lambda/rho) -> RBL_BUF_Q (d doubles, to be summed over ranks) */
+int  rbl_phase_q(rbl_solver* h);
+/* D: replicated w-step from the summed q (algorithms.py:109-116,190-207) */
+int  rbl_phase_w(rbl_solver* h);
+/* E: v = D w, lambda += rho (z - v), local partial sums -> RBL_BUF_RED (to be summed) */
+int  rbl_phase_dual(rbl_solver* h, int want_objective);
+/* F: residual norms, stop test, rho schedule (algorithms.py:135-157) */
+int  rbl_phase_finish(rbl_solver* h, rbl_stats* out);
+
+/* device buffers the host may pass to a collective */
+enum { RBL_BUF_M = 0, RBL_BUF_Q = 1, RBL_BUF_RED = 2, RBL_BUF_G = 3, RBL_BUF_V = 4, RBL_BUF_Z = 5,
+       RBL_BUF_LAM = 6, RBL_BUF_W = 7, RBL_BUF_COLSTATS = 8 };
+int  rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles);
+/* sum_i sigma_i * loss_(i) of n_total gathered values of v = D w on the device
+ * (objective.py:73-81 without the regulariser) */
+int  rbl_risk_from_v(rbl_solver* h, const void* v_all_dev, double* out);
+/* padded leading dimension of D / G / q / w buffers, CU count, Lipschitz constant of G */
+int  rbl_info(rbl_solver* h, int64_t* ld, int* num_cu, double* lipschitz);
+
+/* ---- measurement ------------------------------------------------------------------ */
+/* accumulated HIP-event time of the two n x d sweep kernels since the last reset */
+enum { RBL_KERNEL_GEMV = 0, RBL_KERNEL_GEMVT = 1 };
+int  rbl_kernel_time(rbl_solver* h, int which, double* total_ms, int64_t* launches);
+int  rbl_reset_kernel_times(rbl_solver* h);
+int  rbl_profile_kernels(rbl_solver* h, int enable);
+
+/* ---- kernel-level entry points over host buffers (parity tests call these) -------- */
+/* element prox (src/util/individual_solver.py:112-123) */
+int  rbl_k_prox(int loss, int64_t n, const double* sigma, double rho, const double* m, double* out);
+/* stable ascending sort of float64 keys with index payload (algorithms.py:92-93) */
+int  rbl_k_sort(int64_t n, const double* keys, double* sorted_keys, uint32_t* perm);
+/* generalised PAV on sorted m (src/util/pav.py:93-178) */
+int  rbl_k_pav(int loss, int64_t n, const double* sigma, double rho, const double* m_sorted,
+               double* out, int64_t* n_merges);
+/* EHRM z-step on sorted m (src/util/PAV_cpt.py:169-293): branch -1 = choose by the
+ * singleton-stage scalar test, 0 = a, 1 = b; *branch_out receives the choice */
+int  rbl_k_pav_ehrm(int64_t n, const double* sigma_a, const double* sigma_b, double B, double rho,
+                    const double* m_sorted, int branch, double* out, int* branch_out);
+/* v = D w and q = D^T c on a host matrix (storage: RBL_STORE_*) */
+int  rbl_k_gemv(int storage, int64_t n, int64_t d, const double* D, const double* w, double* v);
+int  rbl_k_gemvt(int storage, int64_t n, int64_t d, const double* D, const double* c, double* q);
+/* G = D^T D (MFMA f64) */
+int  rbl_k_gram(int storage, int64_t n, int64_t d, const double* D, double* G);
+/* w-steps in Gram space: lasso / ridge / smoothed-l1 */
+int  rbl_k_wstep(int wstep, int64_t d, const double* G, const double* q, double rho, double reg,
+                 double smooth_t, const double* w0, double tol, double* w_out, int* iters);
+/* sigma generators (src/optim/objective.py:97-164) */
+int  rbl_k_weights(int weight_function, int64_t n, const double* args, int n_args,
+                   double* alphas, double* betas);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBL_H */

@@ -259,19 +259,22 @@ def run_traj(X, y, cls, kw, max_iter=200):
 TRAJ = [
     ("erm_bce_l1", 1500, 60, 11, ADMMmethod, dict(weight_function="erm", loss="binary_cross_entropy", l1_reg=0.01), 200),
     ("erm_bce_l2", 1500, 60, 12, ADMMmethod, dict(weight_function="erm", loss="binary_cross_entropy", l2_reg=0.01), 200),
-    ("superq_bce_l2", 1500, 60, 13, ADMMmethod, dict(weight_function="superquantile", loss="binary_cross_entropy", l2_reg=0.01, args=[0.5]), 200),
+    ("superq_bce_l2", 1500, 60, 13, ADMMmethod, dict(weight_function="superquantile", loss="binary_cross_entropy", l2_reg=0.01, args=[0.5]), 500),
     ("extremile_bce_l1", 1200, 40, 14, ADMMmethod, dict(weight_function="extremile", loss="binary_cross_entropy", l1_reg=0.01, args=[2.0]), 200),
     ("esrm_hinge_l2", 1000, 20, 15, ADMMmethod, dict(weight_function="esrm", loss="hinge", l2_reg=0.01, args=[1.0]), 400),
-    ("superq_hinge_l2", 2000, 20, 16, ADMMmethod, dict(weight_function="superquantile", loss="hinge", l2_reg=0.01, args=[0.5]), 400),
+    ("superq_hinge_l2", 2000, 20, 16, ADMMmethod, dict(weight_function="superquantile", loss="hinge", l2_reg=0.01, args=[0.5]), 800),
     ("aorr_hinge_l2", 500, 21, 17, ADMMmethod, dict(weight_function="aorr", loss="hinge", l2_reg=1e-4, args=[0.2, 0.8]), 200),
-    ("aorr_bce_l2", 800, 21, 18, ADMMmethod, dict(weight_function="aorr", loss="binary_cross_entropy", l2_reg=1e-4, args=[0.2, 0.8]), 200),
-    ("ehrm_bce_l2", 1000, 30, 19, ADMMmethod, dict(weight_function="ehrm", loss="binary_cross_entropy", l2_reg=0.01, B=-5), 200),
+    ("aorr_bce_l2", 800, 21, 18, ADMMmethod, dict(weight_function="aorr", loss="binary_cross_entropy", l2_reg=1e-4, args=[0.2, 0.8]), 1000),
+    ("ehrm_bce_l2", 1000, 30, 19, ADMMmethod, dict(weight_function="ehrm", loss="binary_cross_entropy", l2_reg=0.01, B=-5), 700),
     ("sadmm_erm_bce_l1", 1500, 60, 11, smoothADMMmethod, dict(weight_function="erm", loss="binary_cross_entropy", l1_reg=0.01), 200),
 ]
 
 
 def g9():
+    only = os.environ.get("G9_ONLY")
     for name, n, d, seed, cls, kw, mi in TRAJ:
+        if only and name not in only.split(","):
+            continue
         intercept = name.startswith("aorr")
         X, y = problems.make_problem(n, d - 1 if intercept else d, seed, intercept=intercept)
         t0 = time.time()
