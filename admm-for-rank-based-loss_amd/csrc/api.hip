@@ -738,11 +738,9 @@ int rbl_phase_z(rbl_solver* h, const void* m_all_dev) {
 int rbl_phase_q(rbl_solver* h) {
     RBL_ENTER(h);
     if (h->profile) RBL_HIP(hipEventRecord(h->kev[2], h->stream));
-    RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream));
-    if (h->profile) {
-        RBL_HIP(hipEventRecord(h->kev[3], h->stream));
-        h->kev_pending[1] = true;
-    }
+    RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream,
+                         h->profile ? h->kev[3] : nullptr));
+    if (h->profile) h->kev_pending[1] = h->n > 0;
     RBL_HIP(hipEventRecord(h->ev[2], h->stream));
     return RBL_OK;
 }
@@ -797,7 +795,8 @@ int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
     const double dual = std::sqrt(r2[0] > 0.0 ? r2[0] : 0.0);   // algorithms.py:136
     double objective = NAN;
     if (h->want_obj) {
-        double risk = NAN;
+        // sharded rank-weighted runs: the caller adds rbl_risk_from_v() of the gathered v
+        double risk = 0.0;
         if (h->obj_is_risk) risk = r[1];
         else if (!h->sorted_path) risk = r[1] / (double)h->nt;  // erm: sum over ALL ranks of loss / n
         objective = risk;

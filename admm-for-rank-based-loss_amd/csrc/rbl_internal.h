@@ -51,7 +51,7 @@ int launch_gemv(int storage, const void* D, int64_t n, int64_t ld, const double*
 // q = D^T c : partial column sums go to slab (gemvt_slab_rows() x ld doubles), then q
 int gemvt_slab_rows(int num_cu);
 int launch_gemvt(int storage, const void* D, int64_t n, int64_t ld, const double* c, double* slab,
-                 double* q, int num_cu, hipStream_t s);
+                 double* q, int num_cu, hipStream_t s, hipEvent_t main_done = nullptr);
 // D[r0+i][j] = -y[i] * X[i][j] for a chunk of rows already on the device (fp64 staging)
 int launch_form_D(int storage, void* D, int64_t ld, int64_t row0, const double* Xdev, int64_t ldx,
                   const double* ydev, int64_t rows, int64_t d, hipStream_t s);

@@ -397,7 +397,7 @@ int launch_gemv(int storage, const void* D, int64_t n, int64_t ld, const double*
 }
 
 int launch_gemvt(int storage, const void* D, int64_t n, int64_t ld, const double* c, double* slab, double* q,
-                 int num_cu, hipStream_t s) {
+                 int num_cu, hipStream_t s, hipEvent_t main_done) {
     if (n <= 0) {
         RBL_HIP(hipMemsetAsync(q, 0, sizeof(double) * ld, s));
         return RBL_OK;
@@ -407,6 +407,7 @@ int launch_gemvt(int storage, const void* D, int64_t n, int64_t ld, const double
         RBL_TRY((gemvt_T<float, false>((const float*)D, n, ld, c, slab, nullptr, nb, s)));
     else
         RBL_TRY((gemvt_T<double, false>((const double*)D, n, ld, c, slab, nullptr, nb, s)));
+    if (main_done) RBL_HIP(hipEventRecord(main_done, s));  // the sweep kernel alone (roofline timing)
     hipLaunchKernelGGL(k_colreduce, dim3((unsigned)((ld + 63) / 64)), dim3(1024), 0, s, slab, nb, (long long)ld, q);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
