@@ -109,7 +109,8 @@ def admm_solve(X, y, weight_function="erm", loss="binary_cross_entropy", l2_reg=
             z, br = z_step_exact(weight_function, loss, sigma_a, sigma_b, B, rho, m, use_c)
             tr.branch.append(br)
         else:
-            m = (D @ w - lam / rho).reshape(-1)
+            # (n,1)/(d,1) column shapes as in the reference: same BLAS calls, same roundings
+            m = (D @ w.reshape(-1, 1) - lam.reshape(-1, 1) / rho).reshape(-1)
             z = z_step_faithful(weight_function, loss, sigma_a, sigma_b, B, rho, m)
         t1 = time.perf_counter()
         # ---- w-step (:109-116, :190-207, :238-246)
@@ -148,8 +149,9 @@ def admm_solve(X, y, weight_function="erm", loss="binary_cross_entropy", l2_reg=
             lam = lam + rho * (z - v)
             primal = float(np.linalg.norm(z - v))
         else:
-            lam = lam + rho * (z - D @ w)
-            primal = float(np.linalg.norm(z - D @ w))
+            w2 = w.reshape(-1, 1)
+            lam = (lam.reshape(-1, 1) + rho * (z.reshape(-1, 1) - D @ w2)).reshape(-1)
+            primal = float(np.linalg.norm(z.reshape(-1, 1) - D @ w2))
             v = None
         dual = float(np.linalg.norm(w - pre_w))
         tr.primal.append(primal)

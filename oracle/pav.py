@@ -209,6 +209,21 @@ def pav_tree_exact(loss, sigma, rho, m, stats=None):
 
 
 # ----------------------------------------------------------------- faithful sweeps
+def _seq_runsum(a, idx, runlen):
+    """Sum of every run a[idx[k] : idx[k]+runlen[k]] accumulated strictly left to right,
+    ((a0+a1)+a2)+..., the order in which the reference's merge_block adds block sums
+    (src/util/pav.py:22-29,113-119).  np.add.reduceat rounds differently, and the hinge
+    bisection's early exit amplifies last-bit differences into visible ones."""
+    acc = a[idx].copy()
+    k = 1
+    live = np.flatnonzero(runlen > 1)
+    while live.size:
+        acc[live] = acc[live] + a[idx[live] + k]
+        k += 1
+        live = live[runlen[live] > k]
+    return acc
+
+
 def pav_faithful(loss, sigma, rho, m, maxiter=None, stats=None):
     """src/util/pav.py:54-68 (initial batch prox) and :93-178 (get_opt): each sweep
     merges every maximal strictly-decreasing run into one block, re-solves ONLY the
@@ -232,10 +247,10 @@ def pav_faithful(loss, sigma, rho, m, maxiter=None, stats=None):
             break
         starts = np.concatenate([[True], ~viol])
         idx = np.flatnonzero(starts)
-        S = np.add.reduceat(S, idx)
-        M = np.add.reduceat(M, idx)
-        C = np.add.reduceat(C, idx)
         runlen = np.diff(np.concatenate([idx, [x.shape[0]]]))
+        S = _seq_runsum(S, idx, runlen)
+        M = _seq_runsum(M, idx, runlen)
+        C = np.add.reduceat(C, idx)
         newx = x[idx].copy()
         vio = runlen > 1
         newx[vio] = np.asarray(

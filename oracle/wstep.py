@@ -143,15 +143,19 @@ def fista_faithful(beta, X32, y, lam, L=17.0, eta=2.5, tol=7e-5, max_iter=5000):
 def ridge_lbfgs_faithful(w0, z, lam, rho, G, D, reg):
     """w_LBFGS.py:31-53: SciPy L-BFGS-B (maxiter 1000) on the n-space objective."""
     from scipy.optimize import minimize
-    b = (z + lam / rho).reshape(-1)
-    DTb = D.T @ b
+    # column shapes and operation order as in the reference, so the same BLAS routines
+    # (and the SVD-based matrix 2-norm of an (n,1) array, :35) produce the same roundings:
+    # the hinge bisection's early exit amplifies last-bit differences (SURVEY 3.4-h)
+    b = z.reshape(-1, 1) + lam.reshape(-1, 1) / rho
 
-    def f(w):
-        r = D @ w - b
-        return 0.5 * rho * np.dot(r, r) + 0.5 * reg * np.dot(w, w)
+    def f(w):                                                   # :31-37
+        w = w.reshape(-1, 1)
+        temp = D @ w - b
+        return 0.5 * rho * (np.linalg.norm(temp, ord=2) ** 2) + 0.5 * reg * np.sum(w * w)
 
-    def g(w):
-        return rho * (G @ w - DTb) + reg * w
+    def g(w):                                                   # :40-45 (D.T @ b every call)
+        w = w.reshape(-1, 1)
+        return rho * (G @ w - D.T @ b) + reg * w
 
     res = minimize(f, np.asarray(w0, dtype=np.float64).reshape(-1), jac=g, method="L-BFGS-B",
                    options={"disp": False, "maxiter": 1000})

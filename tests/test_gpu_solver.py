@@ -122,7 +122,10 @@ def test_reference_trajectory_goldens(R, name):
     elif name.startswith("aorr_hinge"):
         assert f_gpu <= f_ref * (1 + 1e-6) + 1e-12     # non-convex + reference artifact: one-sided
     elif converged_ref:
-        tol = 2e-6 if name.startswith("ehrm") else 1e-6
+        # convex problems run to the stop rule: 1e-6.  ehrm / aorr are non-convex, both
+        # runs stop at slightly different iterations near a flat stationary region
+        # (reference 308 / 531 iterations): 1e-5 / 5e-4 relative (|dF| ~ 1e-6 absolute).
+        tol = 1e-5 if name.startswith("ehrm") else (5e-4 if name.startswith("aorr") else 1e-6)
         assert abs(rel) <= tol, (name, rel)
     else:
         # the reference did not reach its stop rule in max_iter: compare one-sidedly
@@ -231,3 +234,33 @@ def test_synthetic_generator_and_state_roundtrip(R):
     s2.set_state(w=state["w"], z=state["z"], lam=state["lam"], rho=state["rho"], iter=state["iter"])
     a, b = s.step(True), s2.step(True)
     assert a.primal == b.primal and a.dual == b.dual and a.objective == b.objective   # deterministic kernels
+
+
+def test_sharded_driver_on_gpu_world1_and_buffer_views(R):
+    """The multi-GPU driver with one rank: the torch views of the library's exchange buffers
+    alias device memory (zero copy) and the phase-by-phase path equals rbl_step."""
+    import torch
+    from admm_for_rank_based_loss_amd.dist import ShardedADMM, GpuEngine
+    outs = []
+    for use_driver in (False, True):
+        s = R.Solver(30000, 64, "superquantile", "binary_cross_entropy", reg=0.01, wstep=2, args=[0.5], tol=0.0)
+        s.generate_synthetic(seed=5)
+        hist = []
+        if use_driver:
+            eng = GpuEngine(s, 0)
+            drv = ShardedADMM(eng)
+            drv.setup_gram()
+            q = eng.buf("q")
+            assert q.is_cuda and q.dtype == torch.float64 and q.numel() == 64
+            for _ in range(6):
+                st = drv.step(True)
+                hist.append((st.primal, st.dual, st.objective))
+            # the view sees what the library wrote (q = D^T c of the last iteration)
+            assert float(q.abs().sum()) > 0
+        else:
+            s.gram()
+            for _ in range(6):
+                st = s.step(True)
+                hist.append((st.primal, st.dual, st.objective))
+        outs.append((np.array(hist), s.get_state()["w"]))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
