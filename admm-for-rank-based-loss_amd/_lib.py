@@ -105,6 +105,27 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so
+    (same SONAME as /opt/rocm's).  If librbl.so pulls in the system copy first and torch
+    initialises its bundled copy later, the process holds two HIP runtimes and torch then
+    reports "No HIP GPUs are available" (measured on the MI355X box, tools/diag_hip_runtime.py).
+    Loading torch's copy first makes librbl.so resolve to it as well, whichever module is
+    imported first.  Set RBL_NO_TORCH_HIP_PRELOAD=1 to use the system runtime."""
+    if os.environ.get("RBL_NO_TORCH_HIP_PRELOAD") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass    # without torch the system runtime is the only one: nothing to reconcile
+
+
 def load():
     """Load librbl.so; raises (never falls back) when the HIP library is not built."""
     global _lib
@@ -113,6 +134,7 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _preload_torch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
