@@ -142,7 +142,9 @@ class Solver:
         return out
 
     def set_stream(self, stream_ptr):
-        _lib.check(self.lib.rbl_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
+        """hipStream_t as an integer (0 = the default stream); None = the handle's own stream."""
+        p = C.c_void_p(-1) if stream_ptr is None else C.c_void_p(int(stream_ptr))
+        _lib.check(self.lib.rbl_set_stream(self._h, p))
 
     # --------------------------------------------------------------------- state
     def get_state(self, want_z=True, want_lam=True):

@@ -473,7 +473,9 @@ fail:
 int rbl_set_stream(rbl_solver* h, void* hip_stream) {
     RBL_ENTER(h);
     RBL_HIP(hipStreamSynchronize(h->stream));
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    // NULL is a real stream (the legacy default stream torch uses unless told otherwise);
+    // (void*)-1 restores the handle's own non-blocking stream
+    h->stream = (hip_stream == (void*)-1) ? h->own_stream : (hipStream_t)hip_stream;
     return RBL_OK;
 }
 

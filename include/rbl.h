@@ -101,7 +101,8 @@ int  rbl_device_count(void);
 /* Optimizer.__init__ / rankbasedObjective.__init__ */
 int  rbl_create(const rbl_config* cfg, rbl_solver** out);
 int  rbl_destroy(rbl_solver* h);
-/* run the library's kernels on this hipStream_t (NULL = the handle's own stream) */
+/* run the library's kernels on this hipStream_t: NULL is the (legacy) default stream,
+ * (void*)-1 goes back to the handle's own non-blocking stream (the initial setting) */
 int  rbl_set_stream(rbl_solver* h, void* hip_stream);
 
 /* ---- data: D = -y * X (algorithms.py:23), G = D^T D (algorithms.py:24) ---------- */
