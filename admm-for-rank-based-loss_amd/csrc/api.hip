@@ -175,7 +175,7 @@ int alloc_wstep(WstepWorkspace& ww, int64_t ld) {
     RBL_TRY(dev_alloc(&ww.r, (size_t)ld));
     RBL_TRY(dev_alloc(&ww.p, (size_t)ld));
     RBL_TRY(dev_alloc(&ww.scal, 8));
-    RBL_TRY(dev_alloc(&ww.flags, 4));
+    RBL_TRY(dev_alloc(&ww.flags, 8));
     return RBL_OK;
 }
 
@@ -1241,7 +1241,7 @@ int rbl_k_wstep(int wstep, int64_t d, const double* G, const double* q, double r
     ww.r = sc.alloc<double>((size_t)ld);
     ww.p = sc.alloc<double>((size_t)ld);
     ww.scal = sc.alloc<double>(8);
-    ww.flags = sc.alloc<int>(4);
+    ww.flags = sc.alloc<int>(8);
     SC_CHECK(ww.yk && ww.Gy && ww.wn && ww.r && ww.p && ww.scal && ww.flags);
     double lam = 0.0;
     RBL_TRY(launch_power_iteration(dG, ld, ww.yk, ww.Gy, ww.scal, 100, &lam, sc.s));

@@ -146,6 +146,9 @@ int launch_power_iteration(const double* G, int64_t d, double* tmp1, double* tmp
 int run_wstep(int wstep, const double* G, int64_t d, const double* q, double rho, double reg, double smooth_t,
               double L, double tol, int max_inner, double* w, WstepWorkspace& ws, int* iters_host,
               hipStream_t s);
+// lasso_fs.hip: exact active-set (feature-sign) lasso in one workgroup; out_dev = 4 ints
+int launch_lasso_fs(const double* G, int64_t ld, int64_t d, const double* q, double* w, double kappa, int* out_dev,
+                    hipStream_t s);
 int launch_diffnorm2(int64_t d, const double* a, const double* b, double* out, hipStream_t s);
 int launch_reg_terms(int64_t d, const double* w, double* out2 /* [sum w^2, sum |w|] */, hipStream_t s);
 int launch_soft_threshold(int64_t d, double* w, double t, hipStream_t s);

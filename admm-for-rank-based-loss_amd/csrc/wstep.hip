@@ -301,6 +301,18 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
             if (hflags[0]) break;
         }
     } else {
+        if (wstep == RBL_WSTEP_L1) {
+            // exact active-set solve first (lasso_fs.hip); FISTA only when the support does not
+            // fit its capacity (e.g. the dense initial w of algorithms.py:42) or it hits its cap
+            int fs[4] = {1, 0, 0, 0};
+            RBL_TRY(launch_lasso_fs(G, ld, ld, q, w, reg / (2.0 * rho), ws.flags + 4, s));
+            RBL_HIP(hipMemcpyAsync(fs, ws.flags + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+            RBL_HIP(hipStreamSynchronize(s));
+            if (fs[0] == 0) {
+                if (iters_host) *iters_host = fs[1];
+                return RBL_OK;
+            }
+        }
         FistaParams P;
         P.mode = (wstep == RBL_WSTEP_L1) ? 0 : 1;
         P.L = L;

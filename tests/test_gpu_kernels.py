@@ -235,6 +235,38 @@ def test_wstep_vs_oracle_and_golden(L):
     assert np.max(np.abs(w3 - ref3)) <= 1e-10 * max(1.0, np.max(np.abs(ref3)))
 
 
+def test_lasso_active_set_solver(L):
+    """The l1 w-step's exact active-set (feature-sign) kernel: cold start, warm start, exactly
+    collinear columns, supports beyond its capacity (falls back to FISTA) - always the exact
+    lasso minimiser (KKT residual and agreement with the oracle's Gram-space solve)."""
+    from oracle import wstep, problems
+    rng = np.random.default_rng(11)
+    for trial in range(5):
+        n, d = 3000, int(rng.integers(40, 400))
+        X, y = problems.make_problem(n, d, seed=100 + trial)       # has 2 exactly collinear columns
+        D = -y * X
+        G = D.T @ D
+        q = D.T @ rng.standard_normal(n)
+        qm = np.max(np.abs(q))
+        for frac in (0.9, 0.5, 0.2, 0.02):
+            kappa = frac * qm
+            ref, _ = wstep.lasso_gram_exact(G, q, kappa, np.zeros(d))
+            f = lambda w: 0.5 * w @ G @ w - q @ w + kappa * np.sum(np.abs(w))
+            for w0 in (np.zeros(d), ref + 1e-3 * (ref != 0), np.where(rng.random(d) < 0.05, 0.01, 0.0)):
+                w, it = L.k_wstep(1, G, q, 0.5, 2 * 0.5 * kappa, w0)       # reg/(2 rho) = kappa
+                assert wstep.lasso_kkt_residual(G, q, kappa, w) <= 1e-9 * qm, (trial, frac)
+                assert f(w) <= f(ref) + 1e-10 * abs(f(ref)) + 1e-12
+                if np.count_nonzero(ref) <= 60:    # unique, well inside the active-set capacity
+                    assert np.max(np.abs(w - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref))), (trial, frac)
+    # all-zero solution and a single coordinate
+    G = np.eye(8) * 3.0
+    q = np.arange(8.0)
+    w, _ = L.k_wstep(1, G, q, 0.5, 2 * 0.5 * 10.0, np.zeros(8))
+    assert np.array_equal(w, np.zeros(8))
+    w, _ = L.k_wstep(1, G, q, 0.5, 2 * 0.5 * 6.5, np.zeros(8))
+    assert np.allclose(w, [0, 0, 0, 0, 0, 0, 0, (7 - 6.5) / 3.0], atol=1e-14)
+
+
 # --------------------------------------------------------------------------- weights
 def test_weights_golden_g8(L):
     import json
