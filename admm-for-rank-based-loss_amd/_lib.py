@@ -17,7 +17,7 @@ WEIGHT = {"erm": 0, "extremile": 1, "superquantile": 2, "esrm": 3, "aorr": 4, "a
 WSTEP_L1, WSTEP_L2, WSTEP_SMOOTH_L1 = 1, 2, 3
 STORAGE = {"f32": 0, "float32": 0, "f64": 1, "float64": 1}
 BUF_M, BUF_Q, BUF_RED, BUF_G, BUF_V, BUF_Z, BUF_LAM, BUF_W, BUF_COLSTATS = range(9)
-KERNEL_GEMV, KERNEL_GEMVT = 0, 1
+KERNEL_GEMV, KERNEL_GEMVT, KERNEL_SWEEP_ERM = 0, 1, 2
 
 
 class RblConfig(C.Structure):
@@ -41,6 +41,7 @@ class RblStats(C.Structure):
         ("objective", C.c_double),
         ("converged", C.c_int32), ("inner_iters", C.c_int32), ("ehrm_branch", C.c_int32), ("pav_merges", C.c_int32),
         ("ms_z", C.c_float), ("ms_q", C.c_float), ("ms_w", C.c_float), ("ms_v", C.c_float), ("ms_total", C.c_float),
+        ("fused", C.c_int32), ("mispredicted", C.c_int32),
     ]
 
 

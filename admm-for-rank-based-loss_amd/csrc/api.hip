@@ -8,6 +8,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <utility>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -64,10 +66,15 @@ struct rbl_solver {
     bool obj_is_risk = false;
 
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};  // gemv begin/end, gemvt begin/end
-    bool profile = false, kev_pending[2] = {false, false};
-    double kt_ms[2] = {0.0, 0.0};
-    int64_t kt_n[2] = {0, 0};
+    hipEvent_t kev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // gemv, gemvt, sweep_erm: begin/end
+    bool profile = false, kev_pending[3] = {false, false, false};
+    double kt_ms[3] = {0.0, 0.0, 0.0};
+    int64_t kt_n[3] = {0, 0, 0};
+
+    // single-sweep erm iteration (sweep_erm.hip)
+    bool fused_ok = false, z_ready = false, p_valid = false, p_pending = false, pred_valid = false, fused_ran = false;
+    double *z_next = nullptr, *p = nullptr, *pred = nullptr;
+    int64_t n_fused = 0, n_mispred = 0;
 };
 
 namespace {
@@ -325,7 +332,7 @@ int rbl_destroy(rbl_solver* h) {
     dev_free(h->D); dev_free(h->w); dev_free(h->w_prev); dev_free(h->q); dev_free(h->G); dev_free(h->w_tmp);
     dev_free(h->z); dev_free(h->lam); dev_free(h->v); dev_free(h->m); dev_free(h->c);
     dev_free(h->sigma_a); dev_free(h->sigma_b); dev_free(h->slab); dev_free(h->partials); dev_free(h->red);
-    dev_free(h->red2); dev_free(h->ysign); dev_free(h->colstats);
+    dev_free(h->red2); dev_free(h->ysign); dev_free(h->colstats); dev_free(h->z_next); dev_free(h->p); dev_free(h->pred);
     free_sort(h->sw);
     free_pav(h->pw);
     dev_free(h->locx_a); dev_free(h->chunk_a); dev_free(h->cph_a); dev_free(h->cpl_a);
@@ -417,7 +424,7 @@ int rbl_create(const rbl_config* cfg, rbl_solver** out) {
             size_t gb = gram_slab_bytes(ld, h->num_cu, n > 0 ? n : 1);
             if (gb > h->slab_bytes) h->slab_bytes = gb;
             CK(dev_alloc(&h->w_prev, (size_t)ld));
-            CK(dev_alloc(&h->q, (size_t)ld));
+            CK(dev_alloc(&h->q, (size_t)ld * 2 + 1));   // [q | D^T lambda seed | ||z||^2]: summed over ranks together
             CK(dev_alloc(&h->G, (size_t)ld * ld));
             CK(dev_alloc(&h->z, (size_t)n));
             CK(dev_alloc(&h->lam, (size_t)n));
@@ -446,7 +453,18 @@ int rbl_create(const rbl_config* cfg, rbl_solver** out) {
             CK(fill_const(h->lam, n, 0.1 * reg / (double)nt, h->stream));
             CK(fill_const(h->z, n, 0.1 * reg / (double)nt, h->stream));
             CK(fill_const(h->w, h->d, 0.001 * reg / (double)h->d / (double)nt, h->stream));
-            CKH(hipMemsetAsync(h->q, 0, sizeof(double) * ld, h->stream));
+            CKH(hipMemsetAsync(h->q, 0, sizeof(double) * (ld * 2 + 1), h->stream));
+            {
+                const char* nf = getenv("RBL_NO_FUSE");
+                h->fused_ok = !h->sorted_path && !(nf && nf[0] == '1') && sweep_erm_supported(h->storage, ld);
+                if (h->fused_ok) {
+                    CK(dev_alloc(&h->z_next, (size_t)n));
+                    CK(dev_alloc(&h->p, (size_t)ld));
+                    CK(dev_alloc(&h->pred, 2));
+                    size_t sb = (size_t)sweep_erm_blocks(h->num_cu) * ld * sizeof(double);
+                    (void)sb;
+                }
+            }
             h->rho = cfg->rho0 > 0.0 ? cfg->rho0 : default_rho(cfg->weight_function);
             h->smooth_t = cfg->smooth_t > 0.0 ? cfg->smooth_t : 1.0;
         }
@@ -669,10 +687,21 @@ int rbl_set_state(rbl_solver* h, const double* w, const double* z, const double*
     if (w) {
         RBL_HIP(hipMemcpy(h->w, w, sizeof(double) * h->d, hipMemcpyHostToDevice));
         h->v_valid = false;
+        h->z_ready = false;
     }
-    if (z && h->z) RBL_HIP(hipMemcpy(h->z, z, sizeof(double) * h->n, hipMemcpyHostToDevice));
-    if (lam && h->lam) RBL_HIP(hipMemcpy(h->lam, lam, sizeof(double) * h->n, hipMemcpyHostToDevice));
-    if (rho) h->rho = *rho;
+    if (z && h->z) {
+        RBL_HIP(hipMemcpy(h->z, z, sizeof(double) * h->n, hipMemcpyHostToDevice));
+        h->z_ready = false;
+    }
+    if (lam && h->lam) {
+        RBL_HIP(hipMemcpy(h->lam, lam, sizeof(double) * h->n, hipMemcpyHostToDevice));
+        h->z_ready = false;
+        h->p_valid = h->p_pending = false;
+    }
+    if (rho) {
+        h->rho = *rho;
+        h->z_ready = false;
+    }
     if (iter) h->iter = *iter;
     if (smooth_t) h->smooth_t = *smooth_t;
     return RBL_OK;
@@ -707,11 +736,19 @@ static int require_ready(rbl_solver* h) {
     return RBL_OK;
 }
 
+// erm problems run ONE sweep of D per iteration (sweep_erm.hip): the pass of iteration k also
+// performs the z-step and the q = D^T c accumulation of iteration k+1.  `z_ready` says that
+// z_next / q / zz already hold that work for rho == the predicted rho_{k+1}; the phases below
+// then skip it.  A wrong prediction only clears the flag (the unfused kernels redo it).
+static inline double* q_pinit(rbl_solver* h) { return h->q + h->ld; }      // D^T lambda (first pass only)
+static inline double* q_zz(rbl_solver* h) { return h->q + 2 * h->ld; }     // ||z||^2 of the current z
+
 int rbl_phase_m(rbl_solver* h) {
     RBL_ENTER(h);
     RBL_TRY(require_ready(h));
     h->step_rho = h->rho;
     RBL_HIP(hipEventRecord(h->ev[0], h->stream));
+    if (h->fused_ok && h->z_ready) return RBL_OK;
     RBL_TRY(ensure_v(h));
     if (h->sorted_path) RBL_TRY(launch_make_m(h->n, h->step_rho, h->v, h->lam, h->m, h->stream));
     return RBL_OK;
@@ -720,8 +757,11 @@ int rbl_phase_m(rbl_solver* h) {
 int rbl_phase_z(rbl_solver* h, const void* m_all_dev) {
     RBL_ENTER(h);
     const double rho = h->step_rho;
-    if (!h->sorted_path) {
+    if (h->fused_ok && h->z_ready) {
+        std::swap(h->z, h->z_next);  // the z-step of this iteration was done by the previous pass
+    } else if (!h->sorted_path) {
         RBL_TRY(launch_erm_zc(h->cfg.loss, h->n, h->sigma0, rho, h->v, h->lam, h->m, h->z, h->c, h->stream));
+        if (h->fused_ok) RBL_TRY(launch_sumsq(h->n, h->z, h->partials, q_zz(h), h->stream));
     } else {
         const double* msrc = (const double*)m_all_dev;
         if (!msrc) {
@@ -739,10 +779,18 @@ int rbl_phase_z(rbl_solver* h, const void* m_all_dev) {
 
 int rbl_phase_q(rbl_solver* h) {
     RBL_ENTER(h);
-    if (h->profile) RBL_HIP(hipEventRecord(h->kev[2], h->stream));
-    RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream,
-                         h->profile ? h->kev[3] : nullptr));
-    if (h->profile) h->kev_pending[1] = h->n > 0;
+    if (!(h->fused_ok && h->z_ready)) {
+        if (h->profile) RBL_HIP(hipEventRecord(h->kev[2], h->stream));
+        RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream,
+                             h->profile ? h->kev[3] : nullptr));
+        if (h->profile) h->kev_pending[1] = h->n > 0;
+        if (h->fused_ok && !h->p_valid) {
+            // D^T lambda seeds the d-space recurrence used to predict the primal residual
+            RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->lam, h->slab, q_pinit(h), h->num_cu, h->stream));
+            h->p_pending = true;
+        }
+    }
+    h->z_ready = false;  // consumed: q (and zz) now belong to the iteration in flight
     RBL_HIP(hipEventRecord(h->ev[2], h->stream));
     return RBL_OK;
 }
@@ -750,26 +798,50 @@ int rbl_phase_q(rbl_solver* h) {
 int rbl_phase_w(rbl_solver* h) {
     RBL_ENTER(h);
     RBL_HIP(hipMemcpyAsync(h->w_prev, h->w, sizeof(double) * h->ld, hipMemcpyDeviceToDevice, h->stream));
+    if (h->p_pending) {
+        RBL_HIP(hipMemcpyAsync(h->p, q_pinit(h), sizeof(double) * h->ld, hipMemcpyDeviceToDevice, h->stream));
+        h->p_pending = false;
+        h->p_valid = true;
+    }
     int wstep = h->cfg.wstep;
     RBL_TRY(run_wstep(wstep, h->G, h->ld, h->q, h->step_rho, h->cfg.reg, h->smooth_t, h->L, h->cfg.w_tol, 100000, h->w,
                       h->ww, &h->inner_iters, h->stream));
     RBL_TRY(launch_diffnorm2(h->ld, h->w, h->w_prev, h->red2, h->stream));
     RBL_TRY(launch_reg_terms(h->ld, h->w, h->red2 + 1, h->stream));
+    h->pred_valid = false;
+    if (h->fused_ok && h->p_valid) {
+        RBL_TRY(launch_symv(h->G, h->ld, h->w, h->ww.Gy, h->stream));
+        RBL_TRY(launch_predict_rho(h->ld, h->q, h->p, h->w, h->ww.Gy, q_zz(h), h->step_rho, 217.0 * (double)h->d,
+                                   h->pred, h->stream));
+        h->pred_valid = true;
+    }
     RBL_HIP(hipEventRecord(h->ev[3], h->stream));
     return RBL_OK;
 }
 
 int rbl_phase_dual(rbl_solver* h, int want_objective) {
     RBL_ENTER(h);
-    if (h->profile) RBL_HIP(hipEventRecord(h->kev[0], h->stream));
-    RBL_TRY(launch_gemv(h->storage, h->D, h->n, h->ld, h->w, h->v, h->num_cu, h->stream));
-    if (h->profile) {
-        RBL_HIP(hipEventRecord(h->kev[1], h->stream));
-        h->kev_pending[0] = true;
+    h->fused_ran = false;
+    if (h->fused_ok && h->pred_valid) {
+        if (h->profile) RBL_HIP(hipEventRecord(h->kev[4], h->stream));
+        RBL_TRY(launch_sweep_erm(h->storage, h->cfg.loss, h->D, h->n, h->ld, h->w, h->z, h->lam, h->v, h->z_next,
+                                 h->sigma0, h->step_rho, h->pred, h->slab, h->partials, h->q, h->red, q_zz(h),
+                                 h->num_cu, h->stream, h->profile ? h->kev[5] : nullptr, want_objective));
+        if (h->profile) h->kev_pending[2] = h->n > 0;
+        h->fused_ran = true;
+        h->v_valid = true;
+        RBL_HIP(hipEventRecord(h->ev[4], h->stream));
+    } else {
+        if (h->profile) RBL_HIP(hipEventRecord(h->kev[0], h->stream));
+        RBL_TRY(launch_gemv(h->storage, h->D, h->n, h->ld, h->w, h->v, h->num_cu, h->stream));
+        if (h->profile) {
+            RBL_HIP(hipEventRecord(h->kev[1], h->stream));
+            h->kev_pending[0] = true;
+        }
+        h->v_valid = true;
+        RBL_HIP(hipEventRecord(h->ev[4], h->stream));
+        RBL_TRY(launch_dual(h->cfg.loss, h->n, h->step_rho, h->z, h->v, h->lam, h->partials, h->red, h->stream));
     }
-    h->v_valid = true;
-    RBL_HIP(hipEventRecord(h->ev[4], h->stream));
-    RBL_TRY(launch_dual(h->cfg.loss, h->n, h->step_rho, h->z, h->v, h->lam, h->partials, h->red, h->stream));
     h->want_obj = want_objective;
     h->obj_is_risk = false;
     if (want_objective && h->sorted_path && h->nt == h->n) {
@@ -782,9 +854,10 @@ int rbl_phase_dual(rbl_solver* h, int want_objective) {
 int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
     RBL_ENTER(h);
     RBL_HIP(hipEventRecord(h->ev[5], h->stream));
-    double r[2], r2[3];
+    double r[2], r2[3], pr[2] = {0.0, 0.0};
     RBL_HIP(hipMemcpyAsync(r, h->red, sizeof(double) * 2, hipMemcpyDeviceToHost, h->stream));
     RBL_HIP(hipMemcpyAsync(r2, h->red2, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
+    if (h->fused_ran) RBL_HIP(hipMemcpyAsync(pr, h->pred, sizeof(double) * 2, hipMemcpyDeviceToHost, h->stream));
     int br = -1;
     unsigned merges = 0;
     if (h->sorted_path) {
@@ -820,13 +893,24 @@ int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
             h->smooth_t = std::fmod(t, std::pow(rho_next, -0.1)) * std::pow((double)i, -0.1);
         }
     }
+    int fused = 0, mispred = 0;
+    if (h->fused_ran) {
+        fused = 1;
+        // the pass already did iteration i+1's z-step with the predicted rho: keep it only if the
+        // exact residual leads to exactly that rho (same double arithmetic on both sides)
+        h->z_ready = !conv && pr[0] == rho_next;
+        if (!conv && !h->z_ready) mispred = 1;
+        h->n_fused += 1;
+        h->n_mispred += mispred;
+    }
+    h->pred_valid = false;
     float ms[5] = {0, 0, 0, 0, 0};
     (void)hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]);
     (void)hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]);
     (void)hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]);
     (void)hipEventElapsedTime(&ms[3], h->ev[3], h->ev[4]);
     (void)hipEventElapsedTime(&ms[4], h->ev[0], h->ev[5]);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         if (h->kev_pending[k]) {
             float t = 0.f;
             if (hipEventElapsedTime(&t, h->kev[2 * k], h->kev[2 * k + 1]) == hipSuccess) {
@@ -853,6 +937,8 @@ int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
         out->ms_w = ms[2];
         out->ms_v = ms[3];
         out->ms_total = ms[4];
+        out->fused = fused;
+        out->mispredicted = mispred;
     }
     h->rho = rho_next;
     h->iter = i + 1;
@@ -938,7 +1024,7 @@ int rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles) {
     int64_t cnt = 0;
     switch (which) {
         case RBL_BUF_M: p = h->m; cnt = h->n; break;
-        case RBL_BUF_Q: p = h->q; cnt = h->ld; break;
+        case RBL_BUF_Q: p = h->q; cnt = h->q ? 2 * h->ld + 1 : 0; break;
         case RBL_BUF_RED: p = h->red; cnt = 2; break;
         case RBL_BUF_G: p = h->G; cnt = h->ld * h->ld; break;
         case RBL_BUF_V: p = h->v; cnt = h->n; break;
@@ -964,7 +1050,7 @@ int rbl_risk_from_v(rbl_solver* h, const void* v_all_dev, double* out) {
 
 int rbl_kernel_time(rbl_solver* h, int which, double* total_ms, int64_t* launches) {
     RBL_ENTER(h);
-    if (which < 0 || which > 1) return RBL_ERR_INVALID;
+    if (which < 0 || which > 2) return RBL_ERR_INVALID;
     if (total_ms) *total_ms = h->kt_ms[which];
     if (launches) *launches = h->kt_n[which];
     return RBL_OK;
@@ -972,8 +1058,8 @@ int rbl_kernel_time(rbl_solver* h, int which, double* total_ms, int64_t* launche
 
 int rbl_reset_kernel_times(rbl_solver* h) {
     RBL_ENTER(h);
-    h->kt_ms[0] = h->kt_ms[1] = 0.0;
-    h->kt_n[0] = h->kt_n[1] = 0;
+    h->kt_ms[0] = h->kt_ms[1] = h->kt_ms[2] = 0.0;
+    h->kt_n[0] = h->kt_n[1] = h->kt_n[2] = 0;
     return RBL_OK;
 }
 

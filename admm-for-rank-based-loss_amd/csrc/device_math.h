@@ -55,6 +55,41 @@ __device__ inline double prox_bce(double sigma, double rho, double m) {
     return x;
 }
 
+// Same root, started from a guess x0 (the previous ADMM iterate of the same sample: z moves
+// little between iterations, so 1-3 Newton steps suffice).  The guess is clamped into the
+// bracket; the safeguards are those of prox_bce, so the result is the same root to rounding.
+__device__ inline double prox_bce_warm(double sigma, double rho, double m, double x0) {
+    double lo = m - sigma / rho, hi = m;
+    double x = fmin(fmax(x0, lo), hi);
+    if (!(x == x)) x = hi;
+    double dxold = hi - lo, dx = dxold;
+    double s, ds;
+    sigmoid2(x, s, ds);
+    double g = sigma * s + rho * (x - m);
+    double h = sigma * ds + rho;
+    if (g < 0.0) lo = x; else hi = x;
+    for (int it = 0; it < 200; ++it) {
+        if (g == 0.0) break;
+        double xn;
+        bool bis = (((x - hi) * h - g) * ((x - lo) * h - g) > 0.0) || (fabs(2.0 * g) > fabs(dxold * h));
+        dxold = dx;
+        if (bis) {
+            dx = 0.5 * (hi - lo);
+            xn = lo + dx;
+        } else {
+            dx = g / h;
+            xn = x - dx;
+        }
+        if (xn == x) break;
+        x = xn;
+        sigmoid2(x, s, ds);
+        g = sigma * s + rho * (x - m);
+        h = sigma * ds + rho;
+        if (g < 0.0) lo = x; else hi = x;
+    }
+    return x;
+}
+
 // Exact hinge prox: the limit of the bisection of src/util/individual_solver.py:11-42.
 __device__ inline double prox_hinge(double sigma, double rho, double m) {
     double a = m - sigma / rho;

@@ -153,6 +153,18 @@ int launch_diffnorm2(int64_t d, const double* a, const double* b, double* out, h
 int launch_reg_terms(int64_t d, const double* w, double* out2 /* [sum w^2, sum |w|] */, hipStream_t s);
 int launch_soft_threshold(int64_t d, double* w, double t, hipStream_t s);
 
+// ---- sweep_erm.hip: one pass over D per iteration for erm (fused dual update + next z-step + D^T c)
+bool sweep_erm_supported(int storage, int64_t ld);
+int sweep_erm_blocks(int num_cu);
+int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld, const double* w, const double* z_old,
+                     double* lam, double* v, double* z_new, double sigma0, double rho, const double* pred_dev,
+                     double* slab, double* partials, double* q, double* red, double* zz_out, int num_cu, hipStream_t s,
+                     hipEvent_t main_done, int want_obj);
+int launch_predict_rho(int64_t ld, const double* q, double* p, const double* w, const double* Gw, const double* zz,
+                       double rho, double cap, double* pred, hipStream_t s);
+int launch_sumsq(int64_t n, const double* x, double* partials, double* out, hipStream_t s);
+int launch_symv(const double* G, int64_t ld, const double* x, double* y, hipStream_t s);
+
 // ---- gram.hip ---------------------------------------------------------------------------
 size_t gram_slab_bytes(int64_t d, int num_cu, int64_t n);
 int launch_gram(int storage, const void* D, int64_t n, int64_t ld, int64_t d, double* slab, double* G,

@@ -343,6 +343,12 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
     return RBL_OK;
 }
 
+int launch_symv(const double* G, int64_t ld, const double* x, double* y, hipStream_t s) {
+    hipLaunchKernelGGL(k_symv, dim3(symv_grid(ld)), dim3(256), 0, s, G, (long long)ld, x, y, 1.0, 0.0, (const int*)nullptr);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
 int launch_diffnorm2(int64_t d, const double* a, const double* b, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_diffnorm2, dim3(1), dim3(UPD_THREADS), 0, s, (long long)d, a, b, out);
     RBL_HIP(hipGetLastError());

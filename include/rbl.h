@@ -90,6 +90,8 @@ typedef struct rbl_stats {
     int32_t ehrm_branch;     /* 0 = a (z<=B), 1 = b (z>=B), -1 = n/a (PAV_cpt.py:222-226) */
     int32_t pav_merges;      /* seam merges performed by the PAV tree, -1 = n/a */
     float   ms_z, ms_q, ms_w, ms_v, ms_total;  /* device time of the phases, HIP events */
+    int32_t fused;           /* 1: this iteration's dual update ran in the single-sweep erm kernel */
+    int32_t mispredicted;    /* 1: rho was mispredicted, the next z-step is redone unfused */
 } rbl_stats;
 
 typedef struct rbl_solver rbl_solver;
@@ -171,7 +173,7 @@ int  rbl_info(rbl_solver* h, int64_t* ld, int* num_cu, double* lipschitz);
 
 /* ---- measurement ------------------------------------------------------------------ */
 /* accumulated HIP-event time of the two n x d sweep kernels since the last reset */
-enum { RBL_KERNEL_GEMV = 0, RBL_KERNEL_GEMVT = 1 };
+enum { RBL_KERNEL_GEMV = 0, RBL_KERNEL_GEMVT = 1, RBL_KERNEL_SWEEP_ERM = 2 };
 int  rbl_kernel_time(rbl_solver* h, int which, double* total_ms, int64_t* launches);
 int  rbl_reset_kernel_times(rbl_solver* h);
 int  rbl_profile_kernels(rbl_solver* h, int enable);

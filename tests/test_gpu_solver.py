@@ -251,7 +251,8 @@ def test_sharded_driver_on_gpu_world1_and_buffer_views(R):
             drv = ShardedADMM(eng)
             drv.setup_gram()
             q = eng.buf("q")
-            assert q.is_cuda and q.dtype == torch.float64 and q.numel() == 64
+            # exchange buffer = [q (ld) | D^T lambda seed (ld) | ||z||^2]: summed over ranks together
+            assert q.is_cuda and q.dtype == torch.float64 and q.numel() == 2 * 64 + 1
             for _ in range(6):
                 st = drv.step(True)
                 hist.append((st.primal, st.dual, st.objective))
