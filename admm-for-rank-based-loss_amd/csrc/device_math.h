@@ -58,13 +58,29 @@ __device__ inline double prox_bce(double sigma, double rho, double m) {
 // Same root, started from a guess x0 (the previous ADMM iterate of the same sample: z moves
 // little between iterations, so 1-3 Newton steps suffice).  The guess is clamped into the
 // bracket; the safeguards are those of prox_bce, so the result is the same root to rounding.
+// This variant sits on the critical path of the single-sweep kernel (2 of 64 lanes active), so
+// it trims the dependent chain: reciprocals by v_rcp_f64 + two Newton refinements (<= 2 ulp)
+// instead of IEEE division, and it stops once an accepted Newton step is below 1e-10 relative
+// (the step after that is O(step^2 * sigma/rho) ~ 1e-17: no further evaluation is needed).
+__device__ inline double fast_rcp(double a) {
+    double r = __builtin_amdgcn_rcp(a);
+    r = __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
+    return r;
+}
+__device__ inline void sigmoid2_fast(double x, double& s, double& ds) {
+    double e = exp(-fabs(x));
+    double inv = fast_rcp(1.0 + e);
+    s = (x > 0.0) ? inv : e * inv;
+    ds = e * inv * inv;
+}
 __device__ inline double prox_bce_warm(double sigma, double rho, double m, double x0) {
     double lo = m - sigma / rho, hi = m;
     double x = fmin(fmax(x0, lo), hi);
     if (!(x == x)) x = hi;
     double dxold = hi - lo, dx = dxold;
     double s, ds;
-    sigmoid2(x, s, ds);
+    sigmoid2_fast(x, s, ds);
     double g = sigma * s + rho * (x - m);
     double h = sigma * ds + rho;
     if (g < 0.0) lo = x; else hi = x;
@@ -77,17 +93,46 @@ __device__ inline double prox_bce_warm(double sigma, double rho, double m, doubl
             dx = 0.5 * (hi - lo);
             xn = lo + dx;
         } else {
-            dx = g / h;
+            dx = g * fast_rcp(h);
             xn = x - dx;
+            if (fabs(dx) <= 1e-10 * (fabs(x) + 1.0)) return xn;  // quadratic convergence: done
         }
         if (xn == x) break;
         x = xn;
-        sigmoid2(x, s, ds);
+        sigmoid2_fast(x, s, ds);
         g = sigma * s + rho * (x - m);
         h = sigma * ds + rho;
         if (g < 0.0) lo = x; else hi = x;
     }
     return x;
+}
+
+// sum over the 64 lanes of a wave, returned to every lane: butterfly inside each 16-lane row
+// with DPP (no LDS round trips), then the four row sums through scalar registers.
+__device__ inline double dpp_mov(double x, const int ctrl_sel) {
+    const long long b = __double_as_longlong(x);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    int rl, rh;
+    switch (ctrl_sel) {
+        case 0: rl = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false); break;   // quad_perm [1,0,3,2]
+        case 1: rl = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false); break;   // quad_perm [2,3,0,1]
+        case 2: rl = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xf, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xf, 0xf, false); break; // row_half_mirror
+        default: rl = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xf, 0xf, false); rh = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xf, 0xf, false); break; // row_mirror
+    }
+    return __longlong_as_double(((long long)rh << 32) | (unsigned int)rl);
+}
+__device__ inline double readlane_d(double x, int lane) {
+    const long long b = __double_as_longlong(x);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ inline double wave_sum_all(double x) {
+    x += dpp_mov(x, 0);
+    x += dpp_mov(x, 1);
+    x += dpp_mov(x, 2);
+    x += dpp_mov(x, 3);   // every lane of a 16-lane row now holds that row's sum
+    return (readlane_d(x, 0) + readlane_d(x, 16)) + (readlane_d(x, 32) + readlane_d(x, 48));
 }
 
 // Exact hinge prox: the limit of the bisection of src/util/individual_solver.py:11-42.

@@ -107,9 +107,7 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
             for (int p = 0; p < P; ++p)
 #pragma unroll
                 for (int k = 0; k < E; ++k) a = __builtin_fma(Pk<T>::at(buf[r][p], k), wr[p][k], a);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
-            dot[r] = a;
+            dot[r] = rbl::wave_sum_all(a);   // DPP butterfly + scalar readlanes: no LDS round trips
         }
         // lane r owns row b*R + r
         double myv = 0.0;
@@ -136,7 +134,7 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
         opaque(buf);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const double cr = __shfl(c, r, 64);
+            const double cr = rbl::readlane_d(c, r);
 #pragma unroll
             for (int p = 0; p < P; ++p)
 #pragma unroll
