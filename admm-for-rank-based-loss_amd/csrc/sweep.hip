@@ -7,6 +7,7 @@
 // Both kernels read D exactly once with 16-byte per-lane loads (1 KiB per wave
 // instruction); they are memory bound: algorithmic bytes = n*ld*sizeof(T) per launch.
 #include "rbl_internal.h"
+#include "device_math.h"
 
 namespace {
 
@@ -110,8 +111,12 @@ __global__ __launch_bounds__(256) void k_gemv(const T* __restrict__ D, long long
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            if constexpr (LPR == 64) {
+                acc[u] = rbl::wave_sum_all(acc[u]);  // DPP butterfly + readlanes (device_math.h)
+            } else {
 #pragma unroll
-            for (int off = LPR / 2; off > 0; off >>= 1) acc[u] += shfl_xor_d(acc[u], off);
+                for (int off = LPR / 2; off > 0; off >>= 1) acc[u] += shfl_xor_d(acc[u], off);
+            }
             long long r = rbase + (long long)u * RPW + rsub;
             if (sub == 0 && r < n) v[r] = acc[u];
         }
