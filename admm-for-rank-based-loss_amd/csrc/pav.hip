@@ -181,25 +181,67 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_seam(double* __restrict__ u,
     long long R1 = seam + half;
     if (R1 > n) R1 = n;
 
-    // s* = first left position whose value exceeds x*  <=>  first i with Psi(u[i]) > 0
-    long long lo = L0, hi = seam - 1;
-    while (lo < hi) {
-        const long long mid = lo + ((hi - lo) >> 1);
-        const double t = u[mid];
-        const long long s = upper_bound_gt(u, mid + 1, seam, t);
-        const long long e = lower_bound_ge(u, seam, R1, t) - 1;
-        if (psi_sign<LOSS>(pa, pm, rho, s, e, t) > 0.0) hi = mid; else lo = mid + 1;
+    // Both boundary functions are monotone in t:  s(t) = first left position with u > t,
+    // e(t) = last right position with u < t.  Every evaluation of Psi therefore narrows the
+    // ranges in which later evaluations have to search ([s_lb,s_ub], [e_lb,e_ub]), and the outer
+    // searches gallop away from the seam, so a cascade that pools k positions costs O(log k)
+    // evaluations with short inner searches instead of O(log^2 of the segment length).
+    long long s_lb = L0, s_ub = seam, e_lb = seam - 1, e_ub = R1 - 1;
+    auto psi_at = [&](double t, long long s_from, long long e_to) -> double {
+        // s in [max(s_from, s_lb), s_ub], e in [e_lb, min(e_to, e_ub)]
+        const long long a = s_from > s_lb ? s_from : s_lb;
+        const long long s = upper_bound_gt(u, a < s_ub ? a : s_ub, s_ub, t);
+        const long long eb = (e_to < e_ub ? e_to : e_ub) + 1;
+        const long long e = lower_bound_ge(u, e_lb + 1 < eb ? e_lb + 1 : eb, eb, t) - 1;
+        const double sg = psi_sign<LOSS>(pa, pm, rho, s, e, t);
+        if (sg > 0.0) {  // x* < t: later probes use smaller t
+            s_ub = s;
+            e_ub = e;
+        } else if (sg < 0.0) {  // x* > t: later probes use larger t
+            s_lb = s;
+            e_lb = e;
+        }
+        return sg;
+    };
+    // s* = first left position whose value exceeds x*  <=>  first i with Psi(u[i]) > 0.
+    // Psi(u[seam-1]) > 0 is known (the seam violates); gallop leftwards from the seam.
+    long long hi = seam - 1, lo = L0 - 1;  // pred(hi) true, pred(lo) false (L0-1: virtual)
+    for (long long off = 1; hi > L0; off <<= 1) {
+        long long p = seam - 1 - off;
+        if (p < L0) p = L0;
+        if (psi_at(u[p], p + 1, R1 - 1) > 0.0) {
+            hi = p;
+        } else {
+            lo = p;
+            break;
+        }
     }
-    const long long s_star = lo;
-    // e* = last right position whose value is below x*  <=>  last j with Psi(u[j]) < 0
+    while (hi - lo > 1) {
+        const long long mid = lo + ((hi - lo) >> 1);
+        if (psi_at(u[mid], mid + 1, R1 - 1) > 0.0) hi = mid; else lo = mid;
+    }
+    const long long s_star = hi;
+    // e* = last right position whose value is below x*  <=>  last j with Psi(u[j]) < 0.
+    // Psi(u[seam]) < 0 is known; gallop rightwards.  The upper bounds found so far stay valid
+    // (a probe above them still sees exactly the pooled sets of the bounding evaluation, whose
+    // sign it inherits); the lower bounds do not (the first probes lie below them): reset.
+    s_lb = L0;
+    e_lb = seam - 1;
     lo = seam;
-    hi = R1 - 1;
-    while (lo < hi) {
-        const long long mid = lo + ((hi - lo + 1) >> 1);
-        const double t = u[mid];
-        const long long s = upper_bound_gt(u, L0, seam, t);
-        const long long e = lower_bound_ge(u, seam, mid, t) - 1;
-        if (psi_sign<LOSS>(pa, pm, rho, s, e, t) < 0.0) lo = mid; else hi = mid - 1;
+    hi = R1;  // pred(lo) true, pred(hi) false (R1: virtual)
+    for (long long off = 1; lo < R1 - 1; off <<= 1) {
+        long long p = seam + off;
+        if (p > R1 - 1) p = R1 - 1;
+        if (psi_at(u[p], L0, p - 1) < 0.0) {
+            lo = p;
+        } else {
+            hi = p;
+            break;
+        }
+    }
+    while (hi - lo > 1) {
+        const long long mid = lo + ((hi - lo) >> 1);
+        if (psi_at(u[mid], L0, mid - 1) < 0.0) lo = mid; else hi = mid;
     }
     const long long e_star = lo;
     const double A = range_sum(pa, s_star, e_star + 1), M = range_sum(pm, s_star, e_star + 1);
