@@ -813,6 +813,17 @@ int rbl_phase_w(rbl_solver* h) {
         RBL_TRY(launch_symv(h->G, h->ld, h->w, h->ww.Gy, h->stream));
         RBL_TRY(launch_predict_rho(h->ld, h->q, h->p, h->w, h->ww.Gy, q_zz(h), h->step_rho, 217.0 * (double)h->d,
                                    h->pred, h->stream));
+        // test hook: RBL_DEBUG_MISPREDICT_EVERY=N corrupts every N-th prediction so that the
+        // verification + unfused recomputation path is exercised (tests/test_gpu_solver.py)
+        static const int mis_every = [] {
+            const char* e = getenv("RBL_DEBUG_MISPREDICT_EVERY");
+            return e ? atoi(e) : 0;
+        }();
+        if (mis_every > 0 && (h->iter % mis_every) == mis_every - 1) {
+            const double wrong = h->step_rho * 1.5;
+            RBL_HIP(hipMemcpyAsync(h->pred, &wrong, sizeof(double), hipMemcpyHostToDevice, h->stream));
+            RBL_HIP(hipStreamSynchronize(h->stream));
+        }
         h->pred_valid = true;
     }
     RBL_HIP(hipEventRecord(h->ev[3], h->stream));

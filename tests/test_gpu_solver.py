@@ -265,3 +265,41 @@ def test_sharded_driver_on_gpu_world1_and_buffer_views(R):
                 hist.append((st.primal, st.dual, st.objective))
         outs.append((np.array(hist), s.get_state()["w"]))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("loss,reg_kind", [("binary_cross_entropy", "l1_reg"), ("hinge", "l2_reg")])
+def test_single_sweep_paths(loss, reg_kind):
+    """erm runs one sweep of D per iteration (sweep_erm.hip).  The same solve (a) fused,
+    (b) with every 3rd rho prediction deliberately corrupted (verification + unfused redo),
+    (c) with the fusion disabled - must give the same iterates, and match the oracle."""
+    import subprocess
+    import sys
+    import os
+    from oracle import problems, admm
+    here = os.path.dirname(os.path.abspath(__file__))
+    runs = {}
+    for name, env in (("fused", {}), ("mispredict", {"RBL_DEBUG_MISPREDICT_EVERY": "3"}), ("unfused", {"RBL_NO_FUSE": "1"})):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, os.path.join(here, "_fused_probe.py"), loss, reg_kind], env=e,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        runs[name] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert runs["fused"]["fused"] >= 38 and runs["fused"]["mispredicted"] == 0
+    assert runs["mispredict"]["mispredicted"] >= 10
+    assert runs["unfused"]["fused"] == 0
+    X, y = problems.make_problem(3000, 160, seed=21)
+    ref = admm.admm_solve(X, y, "erm", loss, max_iter=40, mode="exact", tol=0.0, **{reg_kind: 0.01})
+    tol = 1e-9 if loss == "binary_cross_entropy" else 1e-7
+    for name, r in runs.items():
+        hist = np.array(r["hist"])
+        assert np.allclose(hist[:, 2], ref.rho, rtol=1e-15), name
+        assert np.allclose(hist[:, 0], ref.primal, rtol=tol, atol=tol), name
+        assert np.allclose(hist[:, 3], ref.objective[1:], rtol=tol), name
+        assert np.max(np.abs(np.array(r["w"]) - ref.w)) <= tol * max(1.0, np.max(np.abs(ref.w))), name
+        assert np.max(np.abs(np.array(r["z"]) - ref.z)) <= 10 * tol * max(1.0, np.max(np.abs(ref.z))), name
+    # the three paths agree with each other far below the oracle tolerance
+    for name in ("mispredict", "unfused"):
+        assert np.max(np.abs(np.array(runs[name]["w"]) - np.array(runs["fused"]["w"]))) <= 1e-12
+        assert np.max(np.abs(np.array(runs[name]["lam"]) - np.array(runs["fused"]["lam"]))) <= 1e-12 * max(
+            1.0, np.max(np.abs(runs["fused"]["lam"])))
