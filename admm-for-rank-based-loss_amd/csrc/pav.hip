@@ -204,21 +204,50 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_seam(double* __restrict__ u,
         return sg;
     };
     // s* = first left position whose value exceeds x*  <=>  first i with Psi(u[i]) > 0.
-    // Psi(u[seam-1]) > 0 is known (the seam violates); gallop leftwards from the seam.
+    // Psi(u[seam-1]) > 0 is known (the seam violates); gallop leftwards from the seam (x8 per
+    // step), then close the bracket by interpolating on the VALUES of Psi (it is monotone and
+    // smooth along the positions), falling back to bisection whenever a step fails to halve
+    // the bracket.  A cascade over k positions costs ~log8(k) + a handful of evaluations.
     long long hi = seam - 1, lo = L0 - 1;  // pred(hi) true, pred(lo) false (L0-1: virtual)
-    for (long long off = 1; hi > L0; off <<= 1) {
+    double f_hi = 1.0, f_lo = 0.0;
+    bool have_lo = false, have_hi = false;
+    for (long long off = 1; hi > L0; off <<= 3) {
         long long p = seam - 1 - off;
         if (p < L0) p = L0;
-        if (psi_at(u[p], p + 1, R1 - 1) > 0.0) {
+        const double f = psi_at(u[p], p + 1, R1 - 1);
+        if (f > 0.0) {
             hi = p;
+            f_hi = f;
+            have_hi = true;
         } else {
             lo = p;
+            f_lo = f;
+            have_lo = true;
             break;
         }
     }
+    bool bisect = false;
     while (hi - lo > 1) {
-        const long long mid = lo + ((hi - lo) >> 1);
-        if (psi_at(u[mid], mid + 1, R1 - 1) > 0.0) hi = mid; else lo = mid;
+        const long long span = hi - lo;
+        long long mid = lo + (span >> 1);
+        if (!bisect && have_lo && have_hi) {
+            const double frac = -f_lo / (f_hi - f_lo);
+            long long st = (long long)(frac * (double)span);
+            if (st < 1) st = 1;
+            if (st > span - 1) st = span - 1;
+            mid = lo + st;
+        }
+        const double f = psi_at(u[mid], mid + 1, R1 - 1);
+        if (f > 0.0) {
+            hi = mid;
+            f_hi = f;
+            have_hi = true;
+        } else {
+            lo = mid;
+            f_lo = f;
+            have_lo = true;
+        }
+        bisect = (hi - lo) * 2 > span;  // interpolation did not halve the bracket: bisect next
     }
     const long long s_star = hi;
     // e* = last right position whose value is below x*  <=>  last j with Psi(u[j]) < 0.
@@ -229,19 +258,44 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_seam(double* __restrict__ u,
     e_lb = seam - 1;
     lo = seam;
     hi = R1;  // pred(lo) true, pred(hi) false (R1: virtual)
-    for (long long off = 1; lo < R1 - 1; off <<= 1) {
+    have_lo = have_hi = false;
+    for (long long off = 1; lo < R1 - 1; off <<= 3) {
         long long p = seam + off;
         if (p > R1 - 1) p = R1 - 1;
-        if (psi_at(u[p], L0, p - 1) < 0.0) {
+        const double f = psi_at(u[p], L0, p - 1);
+        if (f < 0.0) {
             lo = p;
+            f_lo = f;
+            have_lo = true;
         } else {
             hi = p;
+            f_hi = f;
+            have_hi = true;
             break;
         }
     }
+    bisect = false;
     while (hi - lo > 1) {
-        const long long mid = lo + ((hi - lo) >> 1);
-        if (psi_at(u[mid], L0, mid - 1) < 0.0) lo = mid; else hi = mid;
+        const long long span = hi - lo;
+        long long mid = lo + (span >> 1);
+        if (!bisect && have_lo && have_hi) {
+            const double frac = -f_lo / (f_hi - f_lo);
+            long long st = (long long)(frac * (double)span);
+            if (st < 1) st = 1;
+            if (st > span - 1) st = span - 1;
+            mid = lo + st;
+        }
+        const double f = psi_at(u[mid], L0, mid - 1);
+        if (f < 0.0) {
+            lo = mid;
+            f_lo = f;
+            have_lo = true;
+        } else {
+            hi = mid;
+            f_hi = f;
+            have_hi = true;
+        }
+        bisect = (hi - lo) * 2 > span;
     }
     const long long e_star = lo;
     const double A = range_sum(pa, s_star, e_star + 1), M = range_sum(pm, s_star, e_star + 1);
