@@ -283,15 +283,11 @@ int z_step_sorted(rbl_solver* h, const double* msrc, double rho) {
     RBL_TRY(launch_unflip_keys(nt, h->sw.keys[0], h->pw.ms, s));
     RBL_TRY(launch_prefix(h->pw.ms, nt, h->pw.locx_m, h->pw.chunk_m, h->pw.cph_m, h->pw.cpl_m, s));
     const bool ehrm = h->cfg.weight_function == RBL_W_EHRM;
-    if (ehrm) {
+    if (ehrm)
         RBL_TRY(launch_ehrm_branch(nt, h->sigma_a, h->sigma_b, h->cfg.B, rho, h->pw.ms, h->pw.partials, h->pw.branch,
                                    -1, s));
-        RBL_TRY(launch_pav_init_ehrm(nt, h->sigma_a, h->sigma_b, rho, h->pw.ms, h->pw.u, h->pw.branch, s));
-    } else {
-        RBL_TRY(launch_pav_init(h->cfg.loss, nt, h->sigma_a, rho, h->pw.ms, h->pw.u, s));
-    }
-    RBL_TRY(launch_pav_tree(h->cfg.loss, nt, rho, h->pw.u, h->pa, h->pb, h->pm, ehrm ? h->pw.branch : nullptr,
-                            h->pw.recs, h->pw.counters, s));
+    RBL_TRY(launch_pav_tree(h->cfg.loss, nt, rho, h->pw.ms, h->sigma_a, h->sigma_b, h->pw.u, h->pa, h->pb, h->pm,
+                            ehrm ? h->pw.branch : nullptr, h->pw.recs, h->pw.counters, s));
     RBL_TRY(launch_scatter_z(nt, h->pw.u, h->sw.vals[0], ehrm ? h->pw.branch : nullptr, h->cfg.B, ehrm ? 1 : 0, rho,
                              h->lam, h->z, h->c, h->off, h->n, s));
     return RBL_OK;
@@ -1226,13 +1222,8 @@ static int k_pav_common(int loss, int64_t n, const double* sigma_a, const double
     RBL_TRY(launch_prefix(sb, n, lx[1], ch[1], cph[1], cpl[1], sc.s));
     RBL_TRY(launch_prefix(ms, n, lx[2], ch[2], cph[2], cpl[2], sc.s));
     Prefix pa{lx[0], cph[0], cpl[0]}, pb{lx[1], cph[1], cpl[1]}, pm{lx[2], cph[2], cpl[2]};
-    if (ehrm) {
-        RBL_TRY(launch_ehrm_branch(n, sa, sb, B, rho, ms, partials, branch, branch_in, sc.s));
-        RBL_TRY(launch_pav_init_ehrm(n, sa, sb, rho, ms, u, branch, sc.s));
-    } else {
-        RBL_TRY(launch_pav_init(loss, n, sa, rho, ms, u, sc.s));
-    }
-    RBL_TRY(launch_pav_tree(loss, n, rho, u, pa, pb, pm, ehrm ? branch : nullptr, recs, counters, sc.s));
+    if (ehrm) RBL_TRY(launch_ehrm_branch(n, sa, sb, B, rho, ms, partials, branch, branch_in, sc.s));
+    RBL_TRY(launch_pav_tree(loss, n, rho, ms, sa, sb, u, pa, pb, pm, ehrm ? branch : nullptr, recs, counters, sc.s));
     // identity permutation scatter applies the EHRM clip
     std::vector<u32> idh((size_t)n);
     for (int64_t i = 0; i < n; ++i) idh[(size_t)i] = (u32)i;

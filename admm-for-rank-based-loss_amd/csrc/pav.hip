@@ -23,7 +23,6 @@
 namespace {
 
 constexpr int PV_THREADS = 256;
-constexpr long long SELF_FILL_MAX_HALF = 512;  // seams of segments up to this size fill their own range
 
 inline unsigned pv_grid(long long n, int threads = PV_THREADS, long long cap = 1 << 20) {
     long long g = (n + threads - 1) / threads;
@@ -132,68 +131,68 @@ __device__ inline double block_value(double ssig, double sm, double cnt, double 
     return rbl::prox<LOSS>(ssig / cnt, rho, sm / cnt);
 }
 
+// ---------------------------------------------------------------- one seam merge
+// Accessors: where u and the prefix sums of sigma / m live.  Global memory for the upper
+// levels, LDS (tile-local indices and plain tile-local prefixes) for the bottom levels.
+struct GlobalAcc {
+    const double* u;
+    Prefix pa, pm;
+    __device__ inline double val(long long i) const { return u[i]; }
+    __device__ inline double sum_a(long long s, long long e1) const { return range_sum(pa, s, e1); }
+    __device__ inline double sum_m(long long s, long long e1) const { return range_sum(pm, s, e1); }
+};
+struct LdsAcc {
+    const double* u;   // tile values
+    const double* pa;  // exclusive prefix of sigma inside the tile (C+1 entries)
+    const double* pm;  // exclusive prefix of m inside the tile
+    __device__ inline double val(long long i) const { return u[i]; }
+    __device__ inline double sum_a(long long s, long long e1) const { return pa[e1] - pa[s]; }
+    __device__ inline double sum_m(long long s, long long e1) const { return pm[e1] - pm[s]; }
+};
+
 // sign of the pooled derivative of positions [s, e] at t:  >0 <=> pooled value < t
-template <int LOSS>
-__device__ inline double psi_sign(const Prefix& pa, const Prefix& pm, double rho, long long s, long long e, double t) {
+template <int LOSS, typename Acc>
+__device__ inline double psi_sign(const Acc& ac, double rho, long long s, long long e, double t) {
     if (e < s) return 0.0;
-    const double A = range_sum(pa, s, e + 1), M = range_sum(pm, s, e + 1), cnt = (double)(e + 1 - s);
+    const double A = ac.sum_a(s, e + 1), M = ac.sum_m(s, e + 1), cnt = (double)(e + 1 - s);
     if (LOSS == 0) return A * rbl::sigmoid1(t) + rho * (cnt * t - M);
     return t - block_value<1>(A, M, cnt, rho);
 }
 
-__device__ inline long long upper_bound_gt(const double* u, long long lo, long long hi, double t) {
+template <typename Acc>
+__device__ inline long long upper_bound_gt(const Acc& ac, long long lo, long long hi, double t) {
     // first i in [lo, hi) with u[i] > t (hi if none); u non-decreasing on [lo, hi)
     while (lo < hi) {
         long long mid = lo + ((hi - lo) >> 1);
-        if (u[mid] > t) hi = mid; else lo = mid + 1;
+        if (ac.val(mid) > t) hi = mid; else lo = mid + 1;
     }
     return lo;
 }
-__device__ inline long long lower_bound_ge(const double* u, long long lo, long long hi, double t) {
+template <typename Acc>
+__device__ inline long long lower_bound_ge(const Acc& ac, long long lo, long long hi, double t) {
     // first j in [lo, hi) with u[j] >= t (hi if none)
     while (lo < hi) {
         long long mid = lo + ((hi - lo) >> 1);
-        if (u[mid] >= t) hi = mid; else lo = mid + 1;
+        if (ac.val(mid) >= t) hi = mid; else lo = mid + 1;
     }
     return lo;
 }
 
-// One thread per seam of a level.  half = 2^(L-1).
-template <int LOSS>
-__global__ __launch_bounds__(PV_THREADS) void k_pav_seam(double* __restrict__ u, long long n, long long half,
-                                                          Prefix pa_, Prefix pb_, Prefix pm, const int* branch,
-                                                          double rho, SeamRec* __restrict__ recs,
-                                                          long long nseams, u32* __restrict__ merge_counter,
-                                                          int self_fill) {
-    const long long k = (long long)blockIdx.x * PV_THREADS + threadIdx.x;
-    if (k >= nseams) return;
-    const long long seam = (2 * k + 1) * half;
-    if (seam >= n) {
-        if (!self_fill) recs[k].s = -1;
-        return;
-    }
-    if (u[seam - 1] <= u[seam]) {  // pav.py:105 - only a strict decrease is a violation
-        if (!self_fill) recs[k].s = -1;
-        return;
-    }
-    const Prefix pa = (branch && *branch) ? pb_ : pa_;
-    const long long L0 = seam - half;
-    long long R1 = seam + half;
-    if (R1 > n) R1 = n;
-
+// Joins the solved segments [L0, seam) and [seam, R1) (seam violates: u[seam-1] > u[seam]).
+// Returns the pooled range [s*, e*] and its value.
+template <int LOSS, typename Acc>
+__device__ inline void seam_merge(const Acc& ac, long long L0, long long seam, long long R1, double rho,
+                                  long long& s_star, long long& e_star, double& x) {
     // Both boundary functions are monotone in t:  s(t) = first left position with u > t,
     // e(t) = last right position with u < t.  Every evaluation of Psi therefore narrows the
-    // ranges in which later evaluations have to search ([s_lb,s_ub], [e_lb,e_ub]), and the outer
-    // searches gallop away from the seam, so a cascade that pools k positions costs O(log k)
-    // evaluations with short inner searches instead of O(log^2 of the segment length).
+    // ranges in which later evaluations have to search ([s_lb,s_ub], [e_lb,e_ub]).
     long long s_lb = L0, s_ub = seam, e_lb = seam - 1, e_ub = R1 - 1;
     auto psi_at = [&](double t, long long s_from, long long e_to) -> double {
-        // s in [max(s_from, s_lb), s_ub], e in [e_lb, min(e_to, e_ub)]
         const long long a = s_from > s_lb ? s_from : s_lb;
-        const long long s = upper_bound_gt(u, a < s_ub ? a : s_ub, s_ub, t);
+        const long long s = upper_bound_gt(ac, a < s_ub ? a : s_ub, s_ub, t);
         const long long eb = (e_to < e_ub ? e_to : e_ub) + 1;
-        const long long e = lower_bound_ge(u, e_lb + 1 < eb ? e_lb + 1 : eb, eb, t) - 1;
-        const double sg = psi_sign<LOSS>(pa, pm, rho, s, e, t);
+        const long long e = lower_bound_ge(ac, e_lb + 1 < eb ? e_lb + 1 : eb, eb, t) - 1;
+        const double sg = psi_sign<LOSS>(ac, rho, s, e, t);
         if (sg > 0.0) {  // x* < t: later probes use smaller t
             s_ub = s;
             e_ub = e;
@@ -205,16 +204,16 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_seam(double* __restrict__ u,
     };
     // s* = first left position whose value exceeds x*  <=>  first i with Psi(u[i]) > 0.
     // Psi(u[seam-1]) > 0 is known (the seam violates); gallop leftwards from the seam (x8 per
-    // step), then close the bracket by interpolating on the VALUES of Psi (it is monotone and
-    // smooth along the positions), falling back to bisection whenever a step fails to halve
-    // the bracket.  A cascade over k positions costs ~log8(k) + a handful of evaluations.
+    // step), then close the bracket by interpolating on the VALUES of Psi (monotone and smooth
+    // along the positions), falling back to bisection whenever a step fails to halve the
+    // bracket.  A cascade over k positions costs ~log8(k) + a handful of evaluations.
     long long hi = seam - 1, lo = L0 - 1;  // pred(hi) true, pred(lo) false (L0-1: virtual)
     double f_hi = 1.0, f_lo = 0.0;
     bool have_lo = false, have_hi = false;
     for (long long off = 1; hi > L0; off <<= 3) {
         long long p = seam - 1 - off;
         if (p < L0) p = L0;
-        const double f = psi_at(u[p], p + 1, R1 - 1);
+        const double f = psi_at(ac.val(p), p + 1, R1 - 1);
         if (f > 0.0) {
             hi = p;
             f_hi = f;
@@ -237,7 +236,7 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_seam(double* __restrict__ u,
             if (st > span - 1) st = span - 1;
             mid = lo + st;
         }
-        const double f = psi_at(u[mid], mid + 1, R1 - 1);
+        const double f = psi_at(ac.val(mid), mid + 1, R1 - 1);
         if (f > 0.0) {
             hi = mid;
             f_hi = f;
@@ -249,7 +248,7 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_seam(double* __restrict__ u,
         }
         bisect = (hi - lo) * 2 > span;  // interpolation did not halve the bracket: bisect next
     }
-    const long long s_star = hi;
+    s_star = hi;
     // e* = last right position whose value is below x*  <=>  last j with Psi(u[j]) < 0.
     // Psi(u[seam]) < 0 is known; gallop rightwards.  The upper bounds found so far stay valid
     // (a probe above them still sees exactly the pooled sets of the bounding evaluation, whose
@@ -262,7 +261,7 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_seam(double* __restrict__ u,
     for (long long off = 1; lo < R1 - 1; off <<= 3) {
         long long p = seam + off;
         if (p > R1 - 1) p = R1 - 1;
-        const double f = psi_at(u[p], L0, p - 1);
+        const double f = psi_at(ac.val(p), L0, p - 1);
         if (f < 0.0) {
             lo = p;
             f_lo = f;
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_seam(double* __restrict__ u,
             if (st > span - 1) st = span - 1;
             mid = lo + st;
         }
-        const double f = psi_at(u[mid], L0, mid - 1);
+        const double f = psi_at(ac.val(mid), L0, mid - 1);
         if (f < 0.0) {
             lo = mid;
             f_lo = f;
@@ -297,17 +296,126 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_seam(double* __restrict__ u,
         }
         bisect = (hi - lo) * 2 > span;
     }
-    const long long e_star = lo;
-    const double A = range_sum(pa, s_star, e_star + 1), M = range_sum(pm, s_star, e_star + 1);
-    const double x = block_value<LOSS>(A, M, (double)(e_star + 1 - s_star), rho);
-    atomicAdd(merge_counter, 1u);
-    if (self_fill) {
-        for (long long i = s_star; i <= e_star; ++i) u[i] = x;
-    } else {
-        recs[k].s = s_star;
-        recs[k].e = e_star;
-        recs[k].x = x;
+    e_star = lo;
+    const double A = ac.sum_a(s_star, e_star + 1), M = ac.sum_m(s_star, e_star + 1);
+    x = block_value<LOSS>(A, M, (double)(e_star + 1 - s_star), rho);
+}
+
+// ---------------------------------------------------------------- bottom of the tree, in LDS
+// One workgroup per tile of PB_TILE sorted positions: element prox (the tree's level 0),
+// tile-local prefix sums and the levels with segments up to PB_TILE, all in LDS; one global
+// read of (m, sigma) and one write of u per position.
+constexpr int PB_TILE_LOG = 11;
+constexpr int PB_TILE = 1 << PB_TILE_LOG;  // 2048 positions, 48 KB of LDS
+constexpr int PB_PER = PB_TILE / PV_THREADS;
+
+template <int LOSS>
+__global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restrict__ ms, const double* __restrict__ sa,
+                                                            const double* __restrict__ sb, const int* __restrict__ branch,
+                                                            double rho, long long n, double* __restrict__ u_out,
+                                                            u32* __restrict__ merge_counter) {
+    __shared__ double su[PB_TILE];
+    __shared__ double spa[PB_TILE + 1];
+    __shared__ double spm[PB_TILE + 1];
+    __shared__ double wsum[2][PV_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long base = (long long)blockIdx.x * PB_TILE;
+    const double* sg = (branch && *branch) ? sb : sa;
+    long long nt = n - base;  // valid positions of this tile
+    if (nt > PB_TILE) nt = PB_TILE;
+
+    // level 0 + thread-local sums (PB_PER consecutive positions per thread)
+    double ls[PB_PER], lm[PB_PER];
+    double ts = 0.0, tm = 0.0;
+#pragma unroll
+    for (int k = 0; k < PB_PER; ++k) {
+        const int i = tid * PB_PER + k;
+        const bool ok = i < nt;
+        ls[k] = ok ? sg[base + i] : 0.0;
+        lm[k] = ok ? ms[base + i] : 0.0;
+        su[i] = ok ? rbl::prox<LOSS>(ls[k], rho, lm[k]) : 0.0;
+        ts += ls[k];
+        tm += lm[k];
     }
+    double is = ts, im = tm;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double ys = __shfl_up(is, off, 64), ym = __shfl_up(im, off, 64);
+        if (lane >= off) {
+            is += ys;
+            im += ym;
+        }
+    }
+    if (lane == 63) {
+        wsum[0][wave] = is;
+        wsum[1][wave] = im;
+    }
+    __syncthreads();
+    double ps = is - ts, pm_ = im - tm;
+    for (int w = 0; w < wave; ++w) {
+        ps += wsum[0][w];
+        pm_ += wsum[1][w];
+    }
+#pragma unroll
+    for (int k = 0; k < PB_PER; ++k) {
+        const int i = tid * PB_PER + k;
+        spa[i] = ps;
+        spm[i] = pm_;
+        ps += ls[k];
+        pm_ += lm[k];
+    }
+    if (tid == PV_THREADS - 1) {
+        spa[PB_TILE] = ps;
+        spm[PB_TILE] = pm_;
+    }
+    __syncthreads();
+
+    const LdsAcc ac{su, spa, spm};
+    u32 merges = 0;
+    for (int half = 1; half < PB_TILE; half <<= 1) {
+        const int nseams = PB_TILE / (2 * half);
+        for (int k = tid; k < nseams; k += PV_THREADS) {
+            const long long seam = (2LL * k + 1) * half;
+            if (seam >= nt) continue;
+            if (su[seam - 1] <= su[seam]) continue;  // pav.py:105: only a strict decrease violates
+            long long R1 = seam + half;
+            if (R1 > nt) R1 = nt;
+            long long s_star, e_star;
+            double x;
+            seam_merge<LOSS>(ac, seam - half, seam, R1, rho, s_star, e_star, x);
+            for (long long i = s_star; i <= e_star; ++i) su[i] = x;  // disjoint from other seams' segments
+            ++merges;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < nt; i += PV_THREADS) u_out[base + i] = su[i];
+    if (merges) atomicAdd(merge_counter, merges);
+}
+
+// ---------------------------------------------------------------- upper levels, global memory
+// One thread per seam of a level.  half = 2^(L-1) >= PB_TILE.
+template <int LOSS>
+__global__ __launch_bounds__(PV_THREADS) void k_pav_seam(double* __restrict__ u, long long n, long long half,
+                                                          Prefix pa_, Prefix pb_, Prefix pm, const int* branch,
+                                                          double rho, SeamRec* __restrict__ recs,
+                                                          long long nseams, u32* __restrict__ merge_counter) {
+    const long long k = (long long)blockIdx.x * PV_THREADS + threadIdx.x;
+    if (k >= nseams) return;
+    const long long seam = (2 * k + 1) * half;
+    if (seam >= n || u[seam - 1] <= u[seam]) {  // pav.py:105 - only a strict decrease is a violation
+        recs[k].s = -1;
+        return;
+    }
+    const GlobalAcc ac{u, (branch && *branch) ? pb_ : pa_, pm};
+    long long R1 = seam + half;
+    if (R1 > n) R1 = n;
+    long long s_star, e_star;
+    double x;
+    seam_merge<LOSS>(ac, seam - half, seam, R1, rho, s_star, e_star, x);
+    atomicAdd(merge_counter, 1u);
+    recs[k].s = s_star;
+    recs[k].e = e_star;
+    recs[k].x = x;
 }
 
 __global__ void k_pav_fill(double* __restrict__ u, long long n, int level_shift, const SeamRec* __restrict__ recs) {
@@ -401,7 +509,7 @@ __global__ void k_scatter_z(long long n, const double* __restrict__ u, const u32
 }  // namespace
 
 int64_t pav_num_chunks(int64_t n) { return n / PAV_CHUNK + 1; }
-int64_t pav_num_recs(int64_t n) { return n / (2 * SELF_FILL_MAX_HALF) + 2; }
+int64_t pav_num_recs(int64_t n) { return n / (2 * PB_TILE) + 2; }
 
 int launch_prefix(const double* x, int64_t n, double* locx, double* chunk_tot, double* cph, double* cpl,
                   hipStream_t s) {
@@ -448,22 +556,31 @@ int launch_pav_init_ehrm(int64_t n, const double* sa, const double* sb, double r
     return RBL_OK;
 }
 
-int launch_pav_tree(int loss, int64_t n, double rho, double* u, Prefix pa, Prefix pb, Prefix pm, const int* branch,
-                    SeamRec* recs, u32* merge_counter, hipStream_t s) {
+int launch_pav_tree(int loss, int64_t n, double rho, const double* ms, const double* sa, const double* sb, double* u,
+                    Prefix pa, Prefix pb, Prefix pm, const int* branch, SeamRec* recs, u32* merge_counter,
+                    hipStream_t s) {
     RBL_HIP(hipMemsetAsync(merge_counter, 0, sizeof(u32), s));
-    int level = 1;
-    for (long long half = 1; half < n; half <<= 1, ++level) {
+    if (n <= 0) return RBL_OK;
+    // levels 0 .. log2(PB_TILE): prox + in-LDS merges, one tile per workgroup
+    const unsigned tiles = (unsigned)((n + PB_TILE - 1) / PB_TILE);
+    if (loss == RBL_LOSS_BCE)
+        hipLaunchKernelGGL(k_pav_bottom<0>, dim3(tiles), dim3(PV_THREADS), 0, s, ms, sa, sb, branch, rho, (long long)n, u,
+                           merge_counter);
+    else
+        hipLaunchKernelGGL(k_pav_bottom<1>, dim3(tiles), dim3(PV_THREADS), 0, s, ms, sa, sb, branch, rho, (long long)n, u,
+                           merge_counter);
+    // upper levels: one thread per seam, pooled ranges written by a fill pass
+    int level = PB_TILE_LOG + 1;
+    for (long long half = PB_TILE; half < n; half <<= 1, ++level) {
         const long long nseams = (n + 2 * half - 1) / (2 * half);
-        const int self_fill = half <= SELF_FILL_MAX_HALF ? 1 : 0;
         const unsigned grid = pv_grid(nseams, PV_THREADS, 1LL << 30);
         if (loss == RBL_LOSS_BCE)
             hipLaunchKernelGGL(k_pav_seam<0>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, half, pa, pb, pm,
-                               branch, rho, recs, nseams, merge_counter, self_fill);
+                               branch, rho, recs, nseams, merge_counter);
         else
             hipLaunchKernelGGL(k_pav_seam<1>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, half, pa, pb, pm,
-                               branch, rho, recs, nseams, merge_counter, self_fill);
-        if (!self_fill)
-            hipLaunchKernelGGL(k_pav_fill, dim3(pv_grid(n)), dim3(256), 0, s, u, (long long)n, level, recs);
+                               branch, rho, recs, nseams, merge_counter);
+        hipLaunchKernelGGL(k_pav_fill, dim3(pv_grid(n)), dim3(256), 0, s, u, (long long)n, level, recs);
     }
     RBL_HIP(hipGetLastError());
     return RBL_OK;

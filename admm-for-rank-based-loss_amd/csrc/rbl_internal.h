@@ -122,9 +122,11 @@ int launch_ehrm_branch(int64_t n, const double* sa, const double* sb, double B, 
                        double* partials, int* branch, int forced, hipStream_t s);
 int launch_pav_init_ehrm(int64_t n, const double* sa, const double* sb, double rho, const double* ms,
                          double* u, const int* branch, hipStream_t s);
-// merge tree over u; sigma prefix: pa (or pa/pb selected by *branch when branch != nullptr)
-int launch_pav_tree(int loss, int64_t n, double rho, double* u, Prefix pa, Prefix pb, Prefix pm,
-                    const int* branch, SeamRec* recs, u32* merge_counter, hipStream_t s);
+// element prox (level 0) + merge tree -> u.  sigma = sa, or sb when *branch != 0 (EHRM); the
+// matching prefix sums are pa / pb.
+int launch_pav_tree(int loss, int64_t n, double rho, const double* ms, const double* sa, const double* sb, double* u,
+                    Prefix pa, Prefix pb, Prefix pm, const int* branch, SeamRec* recs, u32* merge_counter,
+                    hipStream_t s);
 // z[perm[i]] = clip(u[i]); c[perm[i]] = z + lam[perm[i]]/rho  (local slice [off, off+nloc))
 int launch_scatter_z(int64_t n, const double* u, const u32* perm, const int* branch, double B, int has_B,
                      double rho, const double* lam, double* z, double* c, int64_t off, int64_t nloc,
