@@ -303,3 +303,26 @@ def test_single_sweep_paths(loss, reg_kind):
         assert np.max(np.abs(np.array(runs[name]["w"]) - np.array(runs["fused"]["w"]))) <= 1e-12
         assert np.max(np.abs(np.array(runs[name]["lam"]) - np.array(runs["fused"]["lam"]))) <= 1e-12 * max(
             1.0, np.max(np.abs(runs["fused"]["lam"])))
+
+
+@pytest.mark.parametrize("n,d", [(2, 1), (3, 2), (17, 3), (64, 5), (100, 1), (257, 33), (40, 90), (1000, 7)])
+def test_small_and_odd_shapes(R, n, d):
+    """Edge shapes through the whole iteration (single rows, d = 1, d > n, sizes that are not
+    multiples of any tile): 6 iterations against the oracle for an erm and a rank-weighted
+    configuration, both losses."""
+    from oracle import problems, admm
+    rng = np.random.default_rng(n * 131 + d)
+    X = rng.standard_normal((n, d))
+    y = np.where(rng.random((n, 1)) < 0.5, -1, 1).astype(np.int64)
+    cfgs = [dict(weight_function="erm", loss="binary_cross_entropy", l2_reg=0.05),
+            dict(weight_function="erm", loss="hinge", l1_reg=0.05),
+            dict(weight_function="extremile", loss="binary_cross_entropy", l1_reg=0.05, args=[2.0]),
+            dict(weight_function="superquantile", loss="hinge", l2_reg=0.05, args=[0.5])]
+    for kw in cfgs:
+        ref = admm.admm_solve(X, y, max_iter=6, mode="exact", tol=0.0, use_c=True, **kw)
+        s = R.ADMMmethod(X, y, max_iter=6, tol=0.0, storage="f64", **kw)
+        for i in range(6):
+            st = s._s.step(True)
+            assert abs(st.primal - ref.primal[i]) <= 1e-7 * max(1.0, ref.primal[i]), (kw, i)
+            assert abs(st.objective - ref.objective[i + 1]) <= 1e-7 * max(1.0, abs(ref.objective[i + 1])), (kw, i)
+        assert np.max(np.abs(s._s.get_state()["w"] - ref.w)) <= 1e-7 * max(1.0, np.max(np.abs(ref.w))), kw
