@@ -79,6 +79,7 @@ SIGNATURES = {
     "rbl_solve": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(RblStats), _P, _P, _P, _P, _P, C.c_int64]),
     "rbl_finalize_smooth": (C.c_int, [_P]),
     "rbl_objective": (C.c_int, [_P, _P, C.c_int, _D]),
+    "rbl_accuracy": (C.c_int, [_P, _P, C.c_double, _D]),
     "rbl_phase_m": (C.c_int, [_P]),
     "rbl_phase_z": (C.c_int, [_P, _P]),
     "rbl_phase_q": (C.c_int, [_P]),

@@ -206,6 +206,15 @@ class Solver:
         _lib.check(self.lib.rbl_objective(self._h, _lib.ptr(w), 0, C.byref(out)))
         return out.value
 
+    def accuracy(self, w, threshold=0.5):
+        """calculate_accuracy of src/util/calculate_acc.py:3-19 on this handle's rows."""
+        w = _lib.f64(w).reshape(-1)
+        if w.size != self.d:
+            raise ValueError(f"w has {w.size} entries, expected {self.d}")
+        out = C.c_double(0)
+        _lib.check(self.lib.rbl_accuracy(self._h, _lib.ptr(w), float(threshold), C.byref(out)))
+        return out.value
+
     # ---------------------------------------------------------------- phase API
     def phase_m(self):
         _lib.check(self.lib.rbl_phase_m(self._h))

@@ -532,6 +532,9 @@ int rbl_set_data(rbl_solver* h, const double* X, const double* y, int64_t ldx) {
         dev_free(Xd);
         dev_free(yd);
         RBL_TRY(rc);
+        std::vector<signed char> ys((size_t)n);
+        for (int64_t i = 0; i < n; ++i) ys[(size_t)i] = y[i] > 0 ? 1 : -1;
+        RBL_HIP(hipMemcpy(h->ysign, ys.data(), (size_t)n, hipMemcpyHostToDevice));
     }
     h->data_ready = true;
     h->gram_ready = h->gram_local_done = false;
@@ -1022,6 +1025,28 @@ int rbl_objective(rbl_solver* h, const double* w, int include_reg, double* out) 
         else val += 0.5 * h->cfg.reg * r[2];
     }
     *out = val;
+    return RBL_OK;
+}
+
+// fraction of correctly classified rows of this handle's data (src/util/calculate_acc.py:3-19)
+int rbl_accuracy(rbl_solver* h, const double* w, double threshold, double* out) {
+    RBL_ENTER(h);
+    if (!h->data_ready || !w || !out) {
+        rbl_set_error("accuracy: no data or NULL argument");
+        return RBL_ERR_STATE;
+    }
+    if (!(threshold > 0.0 && threshold < 1.0)) {
+        rbl_set_error("accuracy: threshold must be in (0, 1)");
+        return RBL_ERR_INVALID;
+    }
+    RBL_HIP(hipMemcpyAsync(h->w_tmp, w, sizeof(double) * h->d, hipMemcpyHostToDevice, h->stream));
+    RBL_TRY(launch_gemv(h->storage, h->D, h->n, h->ld, h->w_tmp, h->m, h->num_cu, h->stream));
+    RBL_TRY(launch_accuracy(h->cfg.loss, h->n, h->m, h->ysign, std::log(threshold / (1.0 - threshold)), h->partials,
+                            h->red2 + 4, h->stream));
+    double cnt = 0.0;
+    RBL_HIP(hipMemcpyAsync(&cnt, h->red2 + 4, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    *out = h->n > 0 ? cnt / (double)h->n : 0.0;   // local rows; sharded callers average by n
     return RBL_OK;
 }
 

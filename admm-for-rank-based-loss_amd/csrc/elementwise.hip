@@ -131,6 +131,34 @@ __global__ __launch_bounds__(EW_THREADS) void k_loss_sum(long long n, const doub
     if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
 }
 
+// correct predictions of the linear classifier from v = D w = -y (x.w)
+// (reference: src/util/calculate_acc.py:3-19).  tau = logit(threshold).
+//   binary_cross_entropy: predict +1 iff sigmoid(x.w) >= threshold  <=>  x.w >= tau
+//   hinge: the reference maps BOTH outcomes of (x.w >= 0) to +1 (calculate_acc.py:13-15),
+//          i.e. its accuracy is the fraction of y == +1; mirrored as is.
+template <int LOSS>
+__global__ __launch_bounds__(EW_THREADS) void k_accuracy(long long n, const double* __restrict__ v,
+                                                          const signed char* __restrict__ ysign, double tau,
+                                                          double* __restrict__ partials) {
+    __shared__ double smem[EW_THREADS / 64];
+    double acc[1] = {0.0};
+    for (long long i = (long long)blockIdx.x * EW_THREADS + threadIdx.x; i < n;
+         i += (long long)gridDim.x * EW_THREADS) {
+        const int y = ysign[i];
+        bool ok;
+        if (LOSS == 0) {
+            const double xw = -(double)y * v[i];
+            const int pred = (xw >= tau) ? 1 : -1;
+            ok = pred == y;
+        } else {
+            ok = y == 1;
+        }
+        acc[0] += ok ? 1.0 : 0.0;
+    }
+    rbl::block_sum<1, EW_THREADS>(acc, smem);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
 // ---- sigma generators: src/optim/objective.py:97-164 ---------------------------------
 struct WeightParams {
     int wf;
@@ -246,6 +274,13 @@ int launch_sorted_loss_dot(int loss, int64_t n, const u64* sorted_keys, const do
 int launch_loss_sum(int loss, int64_t n, const double* v, double scale, double* partials, double* out,
                     hipStream_t s) {
     LAUNCH_LOSS(k_loss_sum, loss, RED_BLOCKS, EW_THREADS, s, (long long)n, v, scale, partials);
+    RBL_HIP(hipGetLastError());
+    return launch_sum_partials(partials, RED_BLOCKS, 1, out, s);
+}
+
+int launch_accuracy(int loss, int64_t n, const double* v, const signed char* ysign, double tau, double* partials,
+                    double* out, hipStream_t s) {
+    LAUNCH_LOSS(k_accuracy, loss, RED_BLOCKS, EW_THREADS, s, (long long)n, v, ysign, tau, partials);
     RBL_HIP(hipGetLastError());
     return launch_sum_partials(partials, RED_BLOCKS, 1, out, s);
 }

@@ -73,6 +73,8 @@ int launch_prox(int loss, int64_t n, const double* sigma, double rho, const doub
 // lambda += rho (z - v); partial sums {sum (z-v)^2, sum loss(v)} -> red[0..1]
 int launch_dual(int loss, int64_t n, double rho, const double* z, const double* v, double* lam,
                 double* partials, double* red, hipStream_t s);
+int launch_accuracy(int loss, int64_t n, const double* v, const signed char* ysign, double tau, double* partials,
+                    double* out, hipStream_t s);
 int launch_weights(int wf, int64_t n, const double* args, double* alphas, double* betas, hipStream_t s);
 // generic deterministic two-stage reduction helpers
 int reduce_blocks();

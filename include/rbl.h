@@ -146,6 +146,10 @@ int  rbl_finalize_smooth(rbl_solver* h);
 /* rankbasedObjective.get_arrogate_loss(w) (objective.py:71-87); w: d host doubles */
 int  rbl_objective(rbl_solver* h, const double* w, int include_reg, double* out);
 
+/* calculate_accuracy(w, X, y, threshold, loss) of src/util/calculate_acc.py:3-19 on this handle's
+ * rows (hinge mirrors the reference's quirk: every prediction is +1) */
+int  rbl_accuracy(rbl_solver* h, const double* w, double threshold, double* out);
+
 /* ---- phase API (one process per GPU; the host does the collectives in between) ---- */
 /* A: m = D w - lambda/rho for the local rows (algorithms.py:89) -> RBL_BUF_M */
 int  rbl_phase_m(rbl_solver* h);

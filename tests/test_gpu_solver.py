@@ -203,6 +203,24 @@ def test_objective_golden_g7(R):
         assert abs(val - ref) <= 1e-12 * max(1.0, abs(ref)), (cfg, val, ref)
 
 
+def test_accuracy_mirror(R):
+    """calculate_accuracy (reference src/util/calculate_acc.py:3-19), incl. its hinge quirk."""
+    import importlib
+    acc_mod = importlib.import_module("admm_for_rank_based_loss_amd.src.util.calculate_acc")
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((5000, 13))
+    w = rng.standard_normal((13, 1))
+    y = np.where(X @ w + 0.7 * rng.standard_normal((5000, 1)) >= 0, 1, -1)
+    for thr in (0.5, 0.3, 0.8):
+        p = 1 / (1 + np.exp(-(X @ w)))
+        ref = np.mean(np.where(p >= thr, 1, -1) == y)
+        got = acc_mod.calculate_accuracy(w, X, y, threshold=thr, loss="binary_cross_entropy")
+        assert abs(got - ref) <= 2.0 / 5000           # fp32 storage may flip rows sitting on the threshold
+    assert acc_mod.calculate_accuracy(w, X, y, loss="hinge") == np.mean(y == 1)
+    with pytest.raises(ValueError, match="is not supported"):
+        acc_mod.calculate_accuracy(w, X, y, loss="square")
+
+
 def test_z_step_golden_g4(R):
     g = load_golden("g4_zstep.npz")
     for k in range(int(g["ncases"])):
