@@ -87,6 +87,7 @@ SIGNATURES = {
     "rbl_phase_dual": (C.c_int, [_P, C.c_int]),
     "rbl_phase_finish": (C.c_int, [_P, C.POINTER(RblStats)]),
     "rbl_buffer": (C.c_int, [_P, C.c_int, C.POINTER(_P), _I64]),
+    "rbl_pending_reduce": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "rbl_risk_from_v": (C.c_int, [_P, _P, _D]),
     "rbl_info": (C.c_int, [_P, _I64, C.POINTER(C.c_int), _D]),
     "rbl_kernel_time": (C.c_int, [_P, C.c_int, _D, _I64]),

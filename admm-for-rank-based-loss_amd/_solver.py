@@ -241,6 +241,11 @@ class Solver:
         _lib.check(self.lib.rbl_buffer(self._h, int(which), C.byref(p), C.byref(cnt)))
         return p.value, cnt.value
 
+    def pending_reduce(self):
+        m = C.c_int(0)
+        _lib.check(self.lib.rbl_pending_reduce(self._h, C.byref(m)))
+        return m.value
+
     def risk_from_v(self, v_all_ptr):
         out = C.c_double(0)
         _lib.check(self.lib.rbl_risk_from_v(self._h, C.c_void_p(v_all_ptr), C.byref(out)))

@@ -73,6 +73,8 @@ struct rbl_solver {
 
     // single-sweep erm iteration (sweep_erm.hip)
     bool fused_ok = false, z_ready = false, p_valid = false, p_pending = false, pred_valid = false, fused_ran = false;
+    bool red_owned = false;
+    int pending_mask = 0;  // bit 0: the q part, bit 1: the residual part of the exchange buffer awaits a sum over ranks
     double *z_next = nullptr, *p = nullptr, *pred = nullptr;
     int64_t n_fused = 0, n_mispred = 0;
 };
@@ -327,7 +329,8 @@ int rbl_destroy(rbl_solver* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     dev_free(h->D); dev_free(h->w); dev_free(h->w_prev); dev_free(h->q); dev_free(h->G); dev_free(h->w_tmp);
     dev_free(h->z); dev_free(h->lam); dev_free(h->v); dev_free(h->m); dev_free(h->c);
-    dev_free(h->sigma_a); dev_free(h->sigma_b); dev_free(h->slab); dev_free(h->partials); dev_free(h->red);
+    dev_free(h->sigma_a); dev_free(h->sigma_b); dev_free(h->slab); dev_free(h->partials);
+    if (h->red_owned) dev_free(h->red);
     dev_free(h->red2); dev_free(h->ysign); dev_free(h->colstats); dev_free(h->z_next); dev_free(h->p); dev_free(h->pred);
     free_sort(h->sw);
     free_pav(h->pw);
@@ -411,7 +414,10 @@ int rbl_create(const rbl_config* cfg, rbl_solver** out) {
         CK(dev_alloc(&h->sigma_a, (size_t)nt));
         CK(dev_alloc(&h->sigma_b, (size_t)nt));
         CK(dev_alloc(&h->partials, (size_t)reduce_blocks() * 4));
-        CK(dev_alloc(&h->red, 8));
+        if (cfg->objective_only) {
+            CK(dev_alloc(&h->red, 8));
+            h->red_owned = true;
+        }
         CK(dev_alloc(&h->red2, 8));
         CK(dev_alloc(&h->ysign, (size_t)n));
         CK(dev_alloc(&h->colstats, (size_t)ld * 4));
@@ -420,7 +426,10 @@ int rbl_create(const rbl_config* cfg, rbl_solver** out) {
             size_t gb = gram_slab_bytes(ld, h->num_cu, n > 0 ? n : 1);
             if (gb > h->slab_bytes) h->slab_bytes = gb;
             CK(dev_alloc(&h->w_prev, (size_t)ld));
-            CK(dev_alloc(&h->q, (size_t)ld * 2 + 1));   // [q | D^T lambda seed | ||z||^2]: summed over ranks together
+            // one exchange buffer, summed over ranks in at most one collective per iteration:
+            // [q (ld) | D^T lambda seed (ld) | ||z||^2 | primal^2 | sum loss]
+            CK(dev_alloc(&h->q, (size_t)ld * 2 + 3));
+            h->red = h->q + 2 * ld + 1;
             CK(dev_alloc(&h->G, (size_t)ld * ld));
             CK(dev_alloc(&h->z, (size_t)n));
             CK(dev_alloc(&h->lam, (size_t)n));
@@ -449,7 +458,7 @@ int rbl_create(const rbl_config* cfg, rbl_solver** out) {
             CK(fill_const(h->lam, n, 0.1 * reg / (double)nt, h->stream));
             CK(fill_const(h->z, n, 0.1 * reg / (double)nt, h->stream));
             CK(fill_const(h->w, h->d, 0.001 * reg / (double)h->d / (double)nt, h->stream));
-            CKH(hipMemsetAsync(h->q, 0, sizeof(double) * (ld * 2 + 1), h->stream));
+            CKH(hipMemsetAsync(h->q, 0, sizeof(double) * (ld * 2 + 3), h->stream));
             {
                 const char* nf = getenv("RBL_NO_FUSE");
                 h->fused_ok = !h->sorted_path && !(nf && nf[0] == '1') && sweep_erm_supported(h->storage, ld);
@@ -789,6 +798,7 @@ int rbl_phase_q(rbl_solver* h) {
             h->p_pending = true;
         }
     }
+    h->pending_mask = (h->fused_ok && h->z_ready) ? 0 : 1;  // a fused pass' q was already summed with its residuals
     h->z_ready = false;  // consumed: q (and zz) now belong to the iteration in flight
     RBL_HIP(hipEventRecord(h->ev[2], h->stream));
     return RBL_OK;
@@ -852,6 +862,7 @@ int rbl_phase_dual(rbl_solver* h, int want_objective) {
         RBL_HIP(hipEventRecord(h->ev[4], h->stream));
         RBL_TRY(launch_dual(h->cfg.loss, h->n, h->step_rho, h->z, h->v, h->lam, h->partials, h->red, h->stream));
     }
+    h->pending_mask = 2 | (h->fused_ran ? 1 : 0);
     h->want_obj = want_objective;
     h->obj_is_risk = false;
     if (want_objective && h->sorted_path && h->nt == h->n) {
@@ -1056,7 +1067,7 @@ int rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles) {
     int64_t cnt = 0;
     switch (which) {
         case RBL_BUF_M: p = h->m; cnt = h->n; break;
-        case RBL_BUF_Q: p = h->q; cnt = h->q ? 2 * h->ld + 1 : 0; break;
+        case RBL_BUF_Q: p = h->q; cnt = h->q ? 2 * h->ld + 3 : 0; break;  // whole exchange buffer (RED = its tail)
         case RBL_BUF_RED: p = h->red; cnt = 2; break;
         case RBL_BUF_G: p = h->G; cnt = h->ld * h->ld; break;
         case RBL_BUF_V: p = h->v; cnt = h->n; break;
@@ -1098,6 +1109,14 @@ int rbl_reset_kernel_times(rbl_solver* h) {
 int rbl_profile_kernels(rbl_solver* h, int enable) {
     RBL_ENTER(h);
     h->profile = enable != 0;
+    return RBL_OK;
+}
+
+// which part of the exchange buffer (RBL_BUF_Q) has to be summed over the ranks right now:
+// bit 0 = q part [0, 2 ld + 1), bit 1 = residual part [2 ld + 1, 2 ld + 3)
+int rbl_pending_reduce(rbl_solver* h, int* mask) {
+    RBL_ENTER(h);
+    if (mask) *mask = h->pending_mask;
     return RBL_OK;
 }
 

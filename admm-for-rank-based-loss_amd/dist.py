@@ -65,6 +65,9 @@ class GpuEngine:
     def new(self, count):
         return torch.empty(int(count), dtype=torch.float64, device=self.device)
 
+    def pending_reduce(self):
+        return self.s.pending_reduce()
+
     def synth_local(self, seed, class_sep, flip_y):
         self.s.synth_local(seed, class_sep, flip_y)
 
@@ -151,10 +154,26 @@ class ShardedADMM:
             m_all = self._allgather_rows(e.buf("m"))
         e.phase_z(m_all)
         e.phase_q()
-        self._allreduce(e.buf("q"))
-        e.phase_w()
-        e.phase_dual(want_objective)
-        self._allreduce(e.buf("red"))
+        pending = getattr(e, "pending_reduce", None)
+        if pending is None:                       # plain engines: q and the residuals are two buffers
+            self._allreduce(e.buf("q"))
+            e.phase_w()
+            e.phase_dual(want_objective)
+            self._allreduce(e.buf("red"))
+        else:
+            # librbl keeps [q | seed | ||z||^2 | primal^2 | loss] in ONE buffer: a single-sweep erm
+            # iteration needs one collective (after the pass), the unfused path two slices of it
+            x = e.buf("q")
+            nred = e.buf("red").numel()
+            if pending() & 1:
+                self._allreduce(x[: x.numel() - nred])
+            e.phase_w()
+            e.phase_dual(want_objective)
+            m = pending()
+            if m == 3:
+                self._allreduce(x)
+            elif m & 2:
+                self._allreduce(x[x.numel() - nred:])
         st = e.phase_finish()
         if want_objective and e.sorted_path and self.world > 1:
             # rank-weighted objective needs the global order of v: gather it (logging only);

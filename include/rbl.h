@@ -169,6 +169,11 @@ int  rbl_phase_finish(rbl_solver* h, rbl_stats* out);
 enum { RBL_BUF_M = 0, RBL_BUF_Q = 1, RBL_BUF_RED = 2, RBL_BUF_G = 3, RBL_BUF_V = 4, RBL_BUF_Z = 5,
        RBL_BUF_LAM = 6, RBL_BUF_W = 7, RBL_BUF_COLSTATS = 8 };
 int  rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles);
+/* RBL_BUF_Q is the whole exchange buffer [q (ld) | D^T lambda seed (ld) | ||z||^2 | primal^2 |
+ * sum loss]; RBL_BUF_RED is its 2-double tail.  After rbl_phase_q and after rbl_phase_dual this
+ * tells which part awaits the sum over ranks: bit 0 = the first 2 ld + 1 doubles, bit 1 = the
+ * tail; mask 3 = one collective over the whole buffer (single-sweep erm iterations). */
+int  rbl_pending_reduce(rbl_solver* h, int* mask);
 /* sum_i sigma_i * loss_(i) of n_total gathered values of v = D w on the device
  * (objective.py:73-81 without the regulariser) */
 int  rbl_risk_from_v(rbl_solver* h, const void* v_all_dev, double* out);

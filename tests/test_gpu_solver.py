@@ -269,8 +269,9 @@ def test_sharded_driver_on_gpu_world1_and_buffer_views(R):
             drv = ShardedADMM(eng)
             drv.setup_gram()
             q = eng.buf("q")
-            # exchange buffer = [q (ld) | D^T lambda seed (ld) | ||z||^2]: summed over ranks together
-            assert q.is_cuda and q.dtype == torch.float64 and q.numel() == 2 * 64 + 1
+            # exchange buffer = [q (ld) | D^T lambda seed (ld) | ||z||^2 | primal^2 | sum loss]
+            assert q.is_cuda and q.dtype == torch.float64 and q.numel() == 2 * 64 + 3
+            assert eng.buf("red").data_ptr() == q.data_ptr() + 8 * (2 * 64 + 1)
             for _ in range(6):
                 st = drv.step(True)
                 hist.append((st.primal, st.dual, st.objective))
