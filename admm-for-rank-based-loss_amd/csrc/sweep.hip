@@ -100,7 +100,24 @@ __global__ __launch_bounds__(256) void k_gemv(const T* __restrict__ D, long long
 #pragma unroll
                 for (int u = 0; u < U; ++u) Pkt<T>::fma(buf[u][p], wr[p], acc[u]);
         } else {
-            for (long long pk = sub; pk < PK; pk += LPR) {
+            // large d: w lives in LDS; 4 passes x U rows = 16 loads are issued before they are
+            // consumed so that enough bytes stay in flight at the low occupancy LDS leaves
+            constexpr int PB = 4;
+            long long pk = sub;
+            for (; pk + (long long)(PB - 1) * LPR < PK; pk += (long long)PB * LPR) {
+                pkt_t x[PB][U];
+#pragma unroll
+                for (int b = 0; b < PB; ++b)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) x[b][u] = rowp[u][pk + (long long)b * LPR];
+#pragma unroll
+                for (int b = 0; b < PB; ++b) {
+                    const double* wp = sw + (pk + (long long)b * LPR) * E;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) Pkt<T>::fma(x[b][u], wp, acc[u]);
+                }
+            }
+            for (; pk < PK; pk += LPR) {
                 const double* wp = sw + pk * E;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {

@@ -34,6 +34,11 @@ CONFIGS = {
                args=None, B=None, label="SRM erm / BCE / l1=0.01, synthetic 6000000x1000 (BASELINE configs[1])"),
     "C3": dict(rows=10_000_000, cols=1001, weight_function="aorr", loss="hinge", wstep=2, reg=1e-4,
                args=[0.2, 0.8], B=None, label="AoRR aorr[0.2,0.8] / hinge / l2=1e-4, synthetic 10000000x1001"),
+    # one GPU's share of the 8-GPU configurations (BASELINE configs[3], configs[4]) as standalone problems
+    "C4shard": dict(rows=6_250_000, cols=1000, weight_function="ehrm", loss="binary_cross_entropy", wstep=2, reg=0.01,
+                    args=None, B=-5.0, label="EHRM ehrm / BCE / l2=0.01 / B=-5, synthetic 6250000x1000"),
+    "C5shard": dict(rows=1_250_000, cols=10000, weight_function="erm", loss="binary_cross_entropy", wstep=1, reg=0.01,
+                    args=None, B=None, label="SRM erm / BCE / l1=0.01, synthetic 1250000x10000 dense"),
     "C2sq": dict(rows=6_000_000, cols=1000, weight_function="superquantile", loss="binary_cross_entropy", wstep=2,
                  reg=0.01, args=[0.5], B=None, label="SRM superquantile(0.5) / BCE / l2=0.01, synthetic 6000000x1000"),
 }
