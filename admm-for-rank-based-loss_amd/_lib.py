@@ -80,6 +80,7 @@ SIGNATURES = {
     "rbl_finalize_smooth": (C.c_int, [_P]),
     "rbl_objective": (C.c_int, [_P, _P, C.c_int, _D]),
     "rbl_accuracy": (C.c_int, [_P, _P, C.c_double, _D]),
+    "rbl_fair_statistics": (C.c_int, [_P, _P, _P, C.c_double, _P]),
     "rbl_phase_m": (C.c_int, [_P]),
     "rbl_phase_z": (C.c_int, [_P, _P]),
     "rbl_phase_q": (C.c_int, [_P]),

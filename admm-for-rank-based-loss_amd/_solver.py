@@ -215,6 +215,16 @@ class Solver:
         _lib.check(self.lib.rbl_accuracy(self._h, _lib.ptr(w), float(threshold), C.byref(out)))
         return out.value
 
+    def fair_statistics(self, w, group, threshold=0.5):
+        """(SPD, DI, EOD, AOD, TI, FNRD) of src/util/fair_metric.py:3-41 on this handle's rows."""
+        w = _lib.f64(w).reshape(-1)
+        g = _lib.f64(group).reshape(-1)
+        if w.size != self.d or g.size != self.n:
+            raise ValueError("fair_statistics: w / group have the wrong size")
+        out = np.empty(6)
+        _lib.check(self.lib.rbl_fair_statistics(self._h, _lib.ptr(w), _lib.ptr(g), float(threshold), _lib.ptr(out)))
+        return tuple(float(x) for x in out)
+
     # ---------------------------------------------------------------- phase API
     def phase_m(self):
         _lib.check(self.lib.rbl_phase_m(self._h))

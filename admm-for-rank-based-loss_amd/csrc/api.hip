@@ -1112,6 +1112,59 @@ int rbl_profile_kernels(rbl_solver* h, int enable) {
     return RBL_OK;
 }
 
+// SPD, DI, EOD, AOD, TI, FNRD of the linear classifier on this handle's rows
+// (src/util/fair_metric.py:3-41); group: n doubles with values 0 / 1
+int rbl_fair_statistics(rbl_solver* h, const double* w, const double* group, double threshold, double* out6) {
+    RBL_ENTER(h);
+    if (!h->data_ready || !w || !group || !out6) {
+        rbl_set_error("fair_statistics: no data or NULL argument");
+        return RBL_ERR_STATE;
+    }
+    double* gd = nullptr;
+    RBL_TRY(dev_alloc(&gd, (size_t)h->n));
+    int rc = RBL_OK;
+    double c[14];
+    do {
+        if (hipMemcpyAsync(gd, group, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(h->w_tmp, w, sizeof(double) * h->d, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+            rbl_set_error("fair_statistics: upload failed");
+            rc = RBL_ERR_HIP;
+            break;
+        }
+        if ((rc = launch_gemv(h->storage, h->D, h->n, h->ld, h->w_tmp, h->m, h->num_cu, h->stream)) != RBL_OK) break;
+        double* out14 = h->slab;  // scratch (>= 14 doubles)
+        if ((rc = launch_fair_counts(h->n, h->m, h->ysign, gd, threshold, h->partials, out14, h->stream)) != RBL_OK) break;
+        if (hipMemcpyAsync(c, out14, sizeof(double) * 14, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) {
+            rbl_set_error("fair_statistics: readback failed");
+            rc = RBL_ERR_HIP;
+        }
+    } while (0);
+    dev_free(gd);
+    RBL_TRY(rc);
+    // fair_metric.py:11-41, group 0 = G1, group 1 = G2
+    const double G1P = c[1] / c[0], G2P = c[7] / c[6];
+    const double G1TP = c[2], G1FN = c[3], G1TN = c[4], G1FP = c[5];
+    const double G2TP = c[8], G2FN = c[9], G2TN = c[10], G2FP = c[11];
+    const double SPD = G2P - G1P;
+    const double DI = (G1P == 0.0) ? INFINITY : G2P / G1P;
+    const double TPRG1 = G1TP / (G1TP + G1FN), TPRG2 = G2TP / (G2TP + G2FN);
+    const double FPRG1 = G1FP / (G1FP + G1TN), FPRG2 = G2FP / (G2FP + G2TN);
+    const double FNRG1 = G1FN / (G1TP + G1FN), FNRG2 = G2FN / (G2TP + G2FN);
+    const double EOD = TPRG2 - TPRG1;
+    const double AOD = 0.5 * (FPRG2 - FPRG1 + EOD);
+    const double nn = (double)h->n;
+    const double mu = c[12] / nn;
+    const double TI = (c[13] - std::log(mu) * c[12]) / mu / nn;  // sum (b/mu) log(b/mu) / n
+    out6[0] = SPD;
+    out6[1] = DI;
+    out6[2] = EOD;
+    out6[3] = AOD;
+    out6[4] = TI;
+    out6[5] = FNRG2 - FNRG1;
+    return RBL_OK;
+}
+
 // which part of the exchange buffer (RBL_BUF_Q) has to be summed over the ranks right now:
 // bit 0 = q part [0, 2 ld + 1), bit 1 = residual part [2 ld + 1, 2 ld + 3)
 int rbl_pending_reduce(rbl_solver* h, int* mask) {

@@ -159,6 +159,44 @@ __global__ __launch_bounds__(EW_THREADS) void k_accuracy(long long n, const doub
     if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
 }
 
+// Group-wise confusion counts and the Theil-index sums for the fairness statistics the EHRM
+// driver prints (reference: src/util/fair_metric.py:3-41, called from run_EHRM.py:41).
+// partials[b*14 + k]: k = 6*g + {rows, predicted +, TP, FN, TN, FP} for group g in {0,1};
+// k = 12: sum b, k = 13: sum b*log(b) with b = prob - y01 + 1  (fair_metric.py:36-39).
+__global__ __launch_bounds__(EW_THREADS) void k_fair_counts(long long n, const double* __restrict__ v,
+                                                             const signed char* __restrict__ ysign,
+                                                             const double* __restrict__ group, double threshold,
+                                                             double* __restrict__ partials) {
+    __shared__ double smem[14 * EW_THREADS / 64];
+    double acc[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) acc[k] = 0.0;
+    for (long long i = (long long)blockIdx.x * EW_THREADS + threadIdx.x; i < n;
+         i += (long long)gridDim.x * EW_THREADS) {
+        const int y = ysign[i];
+        const double xw = -(double)y * v[i];
+        const double prob = rbl::sigmoid1(xw);                 // fair_metric.py:5-7
+        const int pred = prob >= threshold ? 1 : 0;            // :8
+        const int y01 = y > 0 ? 1 : 0;                         // :9-10
+        const int g = group[i] == 0.0 ? 0 : (group[i] == 1.0 ? 1 : -1);
+        if (g >= 0) {
+            const int o = 6 * g;
+            acc[o + 0] += 1.0;
+            acc[o + 1] += pred;
+            acc[o + 2] += (pred == 1 && y01 == 1);
+            acc[o + 3] += (pred == 0 && y01 == 1);
+            acc[o + 4] += (pred == 0 && y01 == 0);
+            acc[o + 5] += (pred == 1 && y01 == 0);
+        }
+        const double b = prob - (double)y01 + 1.0;
+        acc[12] += b;
+        acc[13] += b * log(b);
+    }
+    rbl::block_sum<14, EW_THREADS>(acc, smem);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 14; ++k) partials[blockIdx.x * 14 + k] = acc[k];
+}
+
 // ---- sigma generators: src/optim/objective.py:97-164 ---------------------------------
 struct WeightParams {
     int wf;
@@ -283,6 +321,16 @@ int launch_accuracy(int loss, int64_t n, const double* v, const signed char* ysi
     LAUNCH_LOSS(k_accuracy, loss, RED_BLOCKS, EW_THREADS, s, (long long)n, v, ysign, tau, partials);
     RBL_HIP(hipGetLastError());
     return launch_sum_partials(partials, RED_BLOCKS, 1, out, s);
+}
+
+int fair_partial_blocks() { return 256; }
+
+int launch_fair_counts(int64_t n, const double* v, const signed char* ysign, const double* group, double threshold,
+                       double* partials, double* out14, hipStream_t s) {
+    hipLaunchKernelGGL(k_fair_counts, dim3(fair_partial_blocks()), dim3(EW_THREADS), 0, s, (long long)n, v, ysign,
+                       group, threshold, partials);
+    RBL_HIP(hipGetLastError());
+    return launch_sum_partials(partials, fair_partial_blocks(), 14, out14, s);
 }
 
 int launch_weights(int wf, int64_t n, const double* args, double* alphas, double* betas, hipStream_t s) {

@@ -75,6 +75,8 @@ int launch_dual(int loss, int64_t n, double rho, const double* z, const double* 
                 double* partials, double* red, hipStream_t s);
 int launch_accuracy(int loss, int64_t n, const double* v, const signed char* ysign, double tau, double* partials,
                     double* out, hipStream_t s);
+int launch_fair_counts(int64_t n, const double* v, const signed char* ysign, const double* group, double threshold,
+                       double* partials, double* out14, hipStream_t s);
 int launch_weights(int wf, int64_t n, const double* args, double* alphas, double* betas, hipStream_t s);
 // generic deterministic two-stage reduction helpers
 int reduce_blocks();

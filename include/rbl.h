@@ -149,6 +149,9 @@ int  rbl_objective(rbl_solver* h, const double* w, int include_reg, double* out)
 /* calculate_accuracy(w, X, y, threshold, loss) of src/util/calculate_acc.py:3-19 on this handle's
  * rows (hinge mirrors the reference's quirk: every prediction is +1) */
 int  rbl_accuracy(rbl_solver* h, const double* w, double threshold, double* out);
+/* calculate_statistics(w, X, label, group, threshold) of src/util/fair_metric.py:3-41 on this
+ * handle's rows: out6 = {SPD, DI, EOD, AOD, TI, FNRD}; group: n doubles (0 / 1) */
+int  rbl_fair_statistics(rbl_solver* h, const double* w, const double* group, double threshold, double* out6);
 
 /* ---- phase API (one process per GPU; the host does the collectives in between) ---- */
 /* A: m = D w - lambda/rho for the local rows (algorithms.py:89) -> RBL_BUF_M */
