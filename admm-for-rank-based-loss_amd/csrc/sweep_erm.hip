@@ -8,10 +8,12 @@
 //     z'_i     = prox(sigma0, rho_{k+1}, m_i)                (individual_solver.py:112-123)
 //     q       += (z'_i + lambda_i / rho_{k+1}) * D_i         (the w-step's D^T c)
 // This kernel does all of it while the row sits in registers: a wave owns R rows at a time
-// (P 16-byte packets per lane and row, as k_gemv), reduces the R dot products with xor
-// shuffles, lanes 0..R-1 do the row-wise update + warm-started prox, the R coefficients are
-// broadcast back and the rows are accumulated into per-lane column sums.  The next batch's
-// loads are issued before the current batch is processed (two register buffers).
+// (P 16-byte packets per lane and row, as k_gemv), reduces the R dot products with DPP
+// butterflies, the R owner lanes do the row-wise update + warm-started prox, the R coefficients
+// are broadcast back and the rows are accumulated into per-lane column sums.  The next
+// sub-batch's loads are issued before the current one is processed (two register buffers);
+// S sub-batches form a super-batch of 16 consecutive rows whose row-wise state is read and
+// written as whole 128-byte lines.
 // rho_{k+1} depends on the GLOBAL primal residual of iteration k; it is predicted in d-space
 // before the pass (k_predict_rho: ||z - D w||^2 = ||z||^2 - 2 (D^T z)'w + w'Gw) and verified
 // after it with the exact residual this kernel accumulates; on a misprediction the host
@@ -22,119 +24,161 @@
 
 namespace {
 
+// a 16-byte packet as loaded by buffer_load_dwordx4
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 template <typename T> struct Pk;
 template <> struct Pk<float> {
     static constexpr int E = 4;
-    typedef float4 type;
-    __device__ static inline double at(const float4& p, int k) {
-        return k == 0 ? (double)p.x : (k == 1 ? (double)p.y : (k == 2 ? (double)p.z : (double)p.w));
-    }
+    __device__ static inline double at(const u32x4& p, int k) { return (double)__uint_as_float(p[k]); }
 };
 template <> struct Pk<double> {
     static constexpr int E = 2;
-    typedef double2 type;
-    __device__ static inline double at(const double2& p, int k) { return k == 0 ? p.x : p.y; }
+    __device__ static inline double at(const u32x4& p, int k) { return __hiloint2double((int)p[2 * k + 1], (int)p[2 * k]); }
 };
 
 constexpr int SE_THREADS = 256;
 
-template <int R, int P>
-__device__ inline void opaque(float4 (&buf)[R][P]) {
+// fp32 storage: hide the packets from the optimiser between the dot phase and the accumulation
+// phase (otherwise the widened fp64 copies of the dot phase are kept alive: 2 VGPRs per element)
+template <typename T, int R, int P>
+__device__ inline void opaque(u32x4 (&buf)[R][P]) {
+    if (sizeof(T) == 4) {
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int p = 0; p < P; ++p)
-            asm volatile("" : "+v"(buf[r][p].x), "+v"(buf[r][p].y), "+v"(buf[r][p].z), "+v"(buf[r][p].w));
+            for (int p = 0; p < P; ++p) asm volatile("" : "+v"(buf[r][p]));
+    }
 }
-template <int R, int P>
-__device__ inline void opaque(double2 (&)[R][P]) {}
 
 // pred[0] = rho_{k+1} (predicted), read on the device so no host round trip is needed
-template <typename T, int LOSS, int P, int R>
+// EXP != 0 only in tools/sweep_lab.hip (ablation timings: which phase costs what); the library
+// instantiates EXP == 0 alone.
+template <typename T, int LOSS, int P, int R, int S, bool WL, int EXP = 0>
 __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
     const T* __restrict__ D, long long n, long long ld, const double* __restrict__ w, const double* __restrict__ z_old,
     double* __restrict__ lam, double* __restrict__ v, double* __restrict__ z_new, double sigma0, double rho,
-    const double* __restrict__ pred, double* __restrict__ slab, double* __restrict__ partials, int want_obj) {
-    typedef typename Pk<T>::type pkt_t;
+    const double* __restrict__ pred, double* __restrict__ slab, double* __restrict__ partials) {
     constexpr int E = Pk<T>::E;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long PK = ld / E;
+    // The wave index goes through readfirstlane: super-batch numbers, row numbers and the row
+    // descriptors are then scalar registers, and a load is buffer_load(SGPR descriptor, 32-bit
+    // per-lane offset) - no 64-bit per-lane addresses, which is what keeps two R x P packet
+    // buffers inside the 256-VGPR budget of 2 waves per SIMD.
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int PK = (int)(ld / E);
+    const unsigned row_bytes = (unsigned)ld * (unsigned)sizeof(T);
     const double rho_next = pred[0];
 
-    double wr[P][E], acc[P][E];
-    long long pk[P];
+    // w: in registers, or (WL) in LDS, one copy per block, laid out [p][lane][k] so that a
+    // lane's E values are contiguous - frees 2*P*E VGPRs for a second pair of row buffers
+    double wr[WL ? 1 : P][E], acc[P][E];
+    __shared__ double sw[WL ? 64 * P * E : 1];
+    int boff[P];   // byte offset of this lane's packet p inside a row
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        pk[p] = lane + 64LL * p;
-        const bool ok = pk[p] < PK;
+        int pkp = lane + 64 * p;
+        const bool ok = pkp < PK;
 #pragma unroll
         for (int k = 0; k < E; ++k) {
-            wr[p][k] = ok ? w[pk[p] * E + k] : 0.0;
+            const double wv = ok ? w[(long long)pkp * E + k] : 0.0;
+            if (WL) {
+                if (wave == 0) sw[(p * 64 + lane) * E + k] = wv;
+            } else {
+                wr[p][k] = wv;
+            }
             acc[p][k] = 0.0;
         }
-        if (!ok) pk[p] = PK - 1;  // tail lanes re-read the last packet; w == 0 and the sums are dropped
+        if (!ok) pkp = PK - 1;  // tail lanes re-read the last packet; w == 0 and the sums are dropped
+        boff[p] = pkp * 16;
     }
-    double s_prim = 0.0, s_loss = 0.0, s_zz = 0.0;
+    if (WL) __syncthreads();
+    double s_prim = 0.0, s_zz = 0.0;
 
-    const long long nbatch = (n + R - 1) / R;
-    const long long gw = (long long)blockIdx.x * (SE_THREADS / 64) + wave;
-    const long long GW = (long long)gridDim.x * (SE_THREADS / 64);
+    // A wave works on super-batches of S*R consecutive rows (S sub-batches of R rows, two
+    // register buffers alternating); lane l < S*R owns row q*S*R + l of super-batch q, so the
+    // row-wise reads (z_old, lambda) and writes (lambda, v, z') of a super-batch are S*R*8
+    // contiguous bytes per array - 128 B for S*R = 16 - instead of R*8-byte fragments (partial
+    // cache-line writes cost ~8% of the pass, tools/sweep_lab.hip).
+    // Super-batch numbers are 32-bit (n < 2^31 * S*R rows) so that all the loop control is SALU:
+    // there is no scalar 64-bit compare.
+    constexpr int SR = S * R;
+    const int nsuper = (int)((n + SR - 1) / SR);
+    const int live_last = (int)(n - (long long)(nsuper - 1) * SR);   // rows of the last super-batch
+    const int gw = (int)blockIdx.x * (SE_THREADS / 64) + wave;
+    const int GW = (int)gridDim.x * (SE_THREADS / 64);
 
-    // Every load of batch b (rows, z_old, lambda) is issued before any load of batch b+1:
-    // s_waitcnt vmcnt counts in issue order, so waiting for batch b then leaves the whole of
-    // batch b+1 in flight (a row-wise load issued later would drain the prefetch).
-    auto load_batch = [&](long long b, pkt_t (&buf)[R][P], double& zo, double& lm) {
-        const long long myrow = b * R + lane;
-        const bool mine = lane < R && myrow < n;
+    // Loads are issued in the order they are consumed: s_waitcnt vmcnt counts in issue order,
+    // so waiting for sub-batch t then leaves the whole of sub-batch t+1 in flight (a row-wise
+    // load issued later than the prefetch would drain it).
+    auto load_side = [&](int q, double& zo, double& lm) {
+        const int live = q == nsuper - 1 ? live_last : SR;
+        const bool mine = lane < live && !(EXP & 32);
+        const long long myrow = (long long)q * SR + lane;
         zo = mine ? z_old[myrow] : 0.0;
         lm = mine ? lam[myrow] : 0.0;
+    };
+    auto load_rows = [&](int q, int sub, u32x4 (&buf)[R][P]) {
+        const int live = q == nsuper - 1 ? live_last : SR;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            long long row = b * R + r;
-            if (row >= n) row = n - 1;
-            const pkt_t* rp = reinterpret_cast<const pkt_t*>(D + row * ld);
+            int i = sub * R + r;
+            if (i >= live) i = live - 1;   // rows past n re-read the last row; their coefficient is 0
+            const long long row = (long long)q * SR + i;
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(D + row * ld), 0, (int)row_bytes, 0x00020000);
 #pragma unroll
-            for (int p = 0; p < P; ++p) buf[r][p] = rp[pk[p]];
+            for (int p = 0; p < P; ++p) buf[r][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[p], 0, 0);
         }
     };
 
-    auto process = [&](long long b, pkt_t (&buf)[R][P], double zo, double lm) {
+    double l_out = 0.0, v_out = 0.0, z_out = 0.0;   // this lane's row of the current super-batch
+    auto process = [&](int live, int sub, u32x4 (&buf)[R][P], double zo, double lm) {
         double dot[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            double a = 0.0;
+        for (int r = 0; r < R; ++r) dot[r] = (EXP & 16) ? Pk<T>::at(buf[r][0], 0) : 0.0;
+        // the LDS offset is made opaque so that the (loop-invariant) reads of w are not hoisted
+        // back into 2*P*E registers
+        int woff = lane * E;
+        if (WL) asm volatile("" : "+v"(woff));
 #pragma unroll
-            for (int p = 0; p < P; ++p)
+        for (int p = 0; p < P; ++p) {
+            if (EXP & 16) break;
+            double wv[E];
 #pragma unroll
-                for (int k = 0; k < E; ++k) a = __builtin_fma(Pk<T>::at(buf[r][p], k), wr[p][k], a);
-            dot[r] = rbl::wave_sum_all(a);   // DPP butterfly + scalar readlanes: no LDS round trips
+            for (int k = 0; k < E; ++k) wv[k] = WL ? sw[p * 64 * E + woff + k] : wr[WL ? 0 : p][k];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int k = 0; k < E; ++k) dot[r] = __builtin_fma(Pk<T>::at(buf[r][p], k), wv[k], dot[r]);
         }
-        // lane r owns row b*R + r
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (!(EXP & 8)) dot[r] = rbl::wave_sum_all(dot[r]);   // DPP butterfly + readlanes: no LDS trips
         double myv = 0.0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) myv = (lane == r) ? dot[r] : myv;
+        for (int r = 0; r < R; ++r) myv = (lane == sub * R + r) ? dot[r] : myv;
         double c = 0.0;
-        const long long row = b * R + lane;
-        if (lane < R && row < n) {
+        if (lane >= sub * R && lane < sub * R + R && lane < live) {
             const double res = zo - myv;
             const double l = lm + rho * res;                       // algorithms.py:132
             s_prim += res * res;                                   // algorithms.py:135
-            if (want_obj) s_loss += rbl::sample_loss<LOSS>(myv);   // objective.py:11-24
             const double lr = l / rho_next;
             const double m = myv - lr;                             // algorithms.py:89 (next iteration)
-            const double zn = (LOSS == 0) ? rbl::prox_bce_warm(sigma0, rho_next, m, zo) : rbl::prox_hinge(sigma0, rho_next, m);
+            const double zn = (EXP & 4) ? m : ((LOSS == 0) ? rbl::prox_bce_warm(sigma0, rho_next, m, zo) : rbl::prox_hinge(sigma0, rho_next, m));
             s_zz += zn * zn;
-            lam[row] = l;
-            v[row] = myv;
-            z_new[row] = zn;
+            l_out = l;
+            v_out = myv;
+            z_out = zn;
             c = zn + lr;
         }
-        // the fp32 -> fp64 widening is redone for the accumulation: keeping the widened copies of
-        // the dot phase alive across the prox would cost 2 VGPRs per element and spill
-        opaque(buf);
+        opaque<T>(buf);
+        if (EXP & 2) {
+            s_zz += c;
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const double cr = rbl::readlane_d(c, r);
+            const double cr = rbl::readlane_d(c, sub * R + r);
 #pragma unroll
             for (int p = 0; p < P; ++p)
 #pragma unroll
@@ -142,19 +186,40 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
         }
     };
 
-    pkt_t bufA[R][P], bufB[R][P];
-    double zoA = 0.0, lmA = 0.0, zoB = 0.0, lmB = 0.0;
-    long long b = gw;
-    if (b < nbatch) load_batch(b, bufA, zoA, lmA);
-    while (b < nbatch) {
-        const long long b1 = b + GW;
-        if (b1 < nbatch) load_batch(b1, bufB, zoB, lmB);
-        process(b, bufA, zoA, lmA);
-        if (b1 >= nbatch) break;
-        const long long b2 = b1 + GW;
-        if (b2 < nbatch) load_batch(b2, bufA, zoA, lmA);
-        process(b1, bufB, zoB, lmB);
-        b = b2;
+    u32x4 bufA[R][P], bufB[R][P];
+    double zo = 0.0, lm = 0.0, zoN = 0.0, lmN = 0.0;
+    int q = gw, sub = 0;
+    if (q < nsuper) {
+        load_side(q, zo, lm);
+        load_rows(q, 0, bufA);
+    }
+    // one flat loop over pairs of sub-batches ((q, sub) in bufA, (q, sub+1) in bufB); q and sub
+    // are scalar registers.  (A nested "for sub" loop lets the compiler hoist the next
+    // super-batch's load addresses out of it and spill them.)
+    while (q < nsuper) {
+        const int live = q == nsuper - 1 ? live_last : SR;
+        load_rows(q, sub + 1, bufB);
+        process(live, sub, bufA, zo, lm);
+        const bool last = sub + 2 == S;
+        const int qn = last ? q + GW : q;
+        const int subn = last ? 0 : sub + 2;
+        if (qn < nsuper) {
+            if (last) load_side(qn, zoN, lmN);
+            load_rows(qn, subn, bufA);
+        }
+        process(live, sub + 1, bufB, zo, lm);
+        if (last) {
+            if (lane < live && !(EXP & 1)) {
+                const long long row = (long long)q * SR + lane;
+                lam[row] = l_out;
+                v[row] = v_out;
+                z_new[row] = z_out;
+            }
+            zo = zoN;
+            lm = lmN;
+        }
+        q = qn;
+        sub = subn;
     }
 
     // fold the 4 waves' column sums in LDS, one slab row per block
@@ -174,7 +239,7 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
         }
     }
     __syncthreads();
-    double sums[3] = {s_prim, s_loss, s_zz};
+    double sums[3] = {s_prim, 0.0, s_zz};   // slot 1: the loss sum, filled by k_loss_sum when wanted
     __shared__ double smem[3 * SE_THREADS / 64];
     rbl::block_sum<3, SE_THREADS>(sums, smem);
     if (tid == 0) {
@@ -256,14 +321,12 @@ __global__ __launch_bounds__(256) void k_sumsq(long long n, const double* __rest
     if (threadIdx.x == 0) partials[blockIdx.x] = a[0];
 }
 
-int g_want_obj = 1;  // set per launch by launch_sweep_erm (host side, single caller thread per handle)
-
-template <typename T, int LOSS, int P, int R>
+template <typename T, int LOSS, int P, int R, int S, bool WL>
 int launch_one(const T* D, long long n, long long ld, const double* w, const double* z_old, double* lam, double* v,
                double* z_new, double sigma0, double rho, const double* pred, double* slab, double* partials, int grid,
                hipStream_t s) {
-    hipLaunchKernelGGL((k_sweep_erm<T, LOSS, P, R>), dim3(grid), dim3(SE_THREADS), 0, s, D, n, ld, w, z_old, lam, v,
-                       z_new, sigma0, rho, pred, slab, partials, g_want_obj);
+    hipLaunchKernelGGL((k_sweep_erm<T, LOSS, P, R, S, WL>), dim3(grid), dim3(SE_THREADS), 0, s, D, n, ld, w, z_old, lam, v,
+                       z_new, sigma0, rho, pred, slab, partials);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }
@@ -274,10 +337,13 @@ int launch_T(const T* D, long long n, long long ld, const double* w, const doubl
              hipStream_t s) {
     const long long PK = ld / Pk<T>::E;
     const long long passes = (PK + 63) / 64;
-    if (passes == 1) return launch_one<T, LOSS, 1, 8>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
-    if (passes == 2) return launch_one<T, LOSS, 2, 4>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
-    if (passes <= 4) return launch_one<T, LOSS, 4, 2>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
-    return launch_one<T, LOSS, 8, 1>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+    if (passes == 1) return launch_one<T, LOSS, 1, 8, 2, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+    if (passes == 2) return launch_one<T, LOSS, 2, 4, 4, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+    if (passes <= 4) return launch_one<T, LOSS, 4, 2, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+    // 5..8 passes only exist for fp64 storage (sweep_erm_supported caps both types at d <= 1024)
+    if constexpr (sizeof(T) == 8)
+        return launch_one<T, LOSS, 8, 1, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+    return RBL_ERR_INVALID;
 }
 
 }  // namespace
@@ -294,7 +360,6 @@ int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld
                      double* lam, double* v, double* z_new, double sigma0, double rho, const double* pred_dev,
                      double* slab, double* partials, double* q, double* red, double* zz_out, int num_cu, hipStream_t s,
                      hipEvent_t main_done, int want_obj) {
-    g_want_obj = want_obj;
     const int grid = sweep_erm_blocks(num_cu);
     int rc;
     if (storage == RBL_STORE_F32) {
@@ -311,6 +376,9 @@ int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld
     hipLaunchKernelGGL(k_colreduce2, dim3((unsigned)((ld + 63) / 64)), dim3(1024), 0, s, slab, grid, (long long)ld, q);
     hipLaunchKernelGGL(k_sum3, dim3(1), dim3(256), 0, s, partials, grid, red, zz_out);
     RBL_HIP(hipGetLastError());
+    // objective.py:11-24: the per-sample losses are summed from v in a pass of their own (8 B per
+    // row) - exp/log1p inside the sweep cost registers on its critical path
+    if (want_obj) RBL_TRY(launch_loss_sum(loss, n, v, 1.0, partials, red + 1, s));
     return RBL_OK;
 }
 

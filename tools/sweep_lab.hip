@@ -1,0 +1,61 @@
+// sweep_lab.hip - ablation timings of k_sweep_erm (not part of the library; built and run by
+// hand:  hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -I../admm-for-rank-based-loss_amd/csrc
+//        tools/sweep_lab.hip -o gpurun_out/sweep_lab).  Prints ms and GB/s per variant.
+#include "../admm-for-rank-based-loss_amd/csrc/sweep_erm.hip"
+#include <cstdio>
+#include <vector>
+
+// stubs for the symbols sweep_erm.hip expects from the rest of the library
+int reduce_blocks() { return 1024; }
+int launch_sum_partials(const double*, int, int, double*, hipStream_t) { return 0; }
+int launch_loss_sum(int, int64_t, const double*, double, double*, double*, hipStream_t) { return 0; }
+void rbl_set_error(const char*, ...) {}
+
+template <int P, int R, int S, bool WL, int EXP>
+static void run(const char* name, const float* D, long long n, long long ld, double* w, double* z, double* lam, double* v,
+                double* zn, double* pred, double* slab, double* partials, int grid) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float best = 1e9f, tot = 0.f;
+    const int reps = 6;
+    for (int i = 0; i < reps + 1; ++i) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((k_sweep_erm<float, 0, P, R, S, WL, EXP>), dim3(grid), dim3(SE_THREADS), 0, 0, D, n, ld, w, z, lam, v, zn,
+                           1.0, 1e-3, pred, slab, partials);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (i) { tot += ms; best = ms < best ? ms : best; }
+    }
+    printf("%-34s P=%d R=%d S=%d WL=%d EXP=%2d grid=%4d  avg %.3f ms  best %.3f ms  %.0f GB/s\n", name, P, R, S, (int)WL, EXP, grid,
+           tot / reps, best, (double)n * ld * 4 / (tot / reps) * 1e-6);
+    fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+    const long long n = argc > 1 ? atoll(argv[1]) : 6000000, ld = 1000;
+    float* D;
+    double *w, *z, *lam, *v, *zn, *pred, *slab, *partials;
+    hipMalloc(&D, n * ld * 4);
+    hipMemsetD32((hipDeviceptr_t)D, 0x3c23d70a /* 0.01f */, n * ld);
+    hipMalloc(&w, ld * 8); hipMalloc(&z, n * 8); hipMalloc(&lam, n * 8); hipMalloc(&v, n * 8); hipMalloc(&zn, n * 8);
+    hipMalloc(&pred, 16); hipMalloc(&slab, 4096 * ld * 8); hipMalloc(&partials, 4096 * 3 * 8);
+    std::vector<double> hw(ld, 1e-3), hz(n, 0.05);
+    double hp[2] = {1.02e-3, 0.0};
+    hipMemcpy(w, hw.data(), ld * 8, hipMemcpyHostToDevice);
+    hipMemcpy(z, hz.data(), n * 8, hipMemcpyHostToDevice);
+    hipMemcpy(lam, hz.data(), n * 8, hipMemcpyHostToDevice);
+    hipMemcpy(pred, hp, 16, hipMemcpyHostToDevice);
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int cu = prop.multiProcessorCount;
+#define RUN(name, P, R, S, WL, EXP, grid) run<P, R, S, WL, EXP>(name, D, n, ld, w, z, lam, v, zn, pred, slab, partials, grid)
+    RUN("full (library) R=2 S=8 regs", 4, 2, 8, false, 0, 2 * cu);
+    RUN("no row writes", 4, 2, 8, false, 1, 2 * cu);
+    RUN("no zo/lm loads, no prox", 4, 2, 8, false, 32 | 4, 2 * cu);
+    RUN("no writes/prox/zo", 4, 2, 8, false, 1 | 4 | 32, 2 * cu);
+    RUN("loads only", 4, 2, 8, false, 1 | 2 | 4 | 8 | 16 | 32, 2 * cu);
+    return 0;
+}
