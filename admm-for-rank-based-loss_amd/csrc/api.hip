@@ -75,7 +75,8 @@ struct rbl_solver {
     bool fused_ok = false, z_ready = false, p_valid = false, p_pending = false, pred_valid = false, fused_ran = false;
     bool red_owned = false;
     int pending_mask = 0;  // bit 0: the q part, bit 1: the residual part of the exchange buffer awaits a sum over ranks
-    double *z_next = nullptr, *p = nullptr, *pred = nullptr;
+    double *z_next = nullptr, *p = nullptr, *p_alt = nullptr, *pred = nullptr;
+    double* hstat = nullptr;   // pinned host block the end-of-iteration statistics are packed into by the device
     int64_t n_fused = 0, n_mispred = 0;
 };
 
@@ -177,6 +178,24 @@ int alloc_prefix(double** locx, double** chunk, double** cph, double** cpl, int6
     return RBL_OK;
 }
 
+// the lasso kernel's status block lives in pinned host memory the device writes directly, and an
+// event marks its completion: the host reads the status without a copy or a stream-wide wait
+int alloc_wstep_pin(WstepWorkspace& ww) {
+    void* pin = nullptr;
+    RBL_HIP(hipHostMalloc(&pin, 64, hipHostMallocDefault));
+    ww.pin = (int*)pin;
+    for (int i = 0; i < 16; ++i) ww.pin[i] = 0;
+    RBL_HIP(hipEventCreateWithFlags(&ww.fs_done, hipEventDisableTiming));
+    return RBL_OK;
+}
+
+void free_wstep_pin(WstepWorkspace& ww) {
+    if (ww.pin) (void)hipHostFree(ww.pin);
+    if (ww.fs_done) (void)hipEventDestroy(ww.fs_done);
+    ww.pin = nullptr;
+    ww.fs_done = nullptr;
+}
+
 int alloc_wstep(WstepWorkspace& ww, int64_t ld) {
     RBL_TRY(dev_alloc(&ww.yk, (size_t)ld));
     RBL_TRY(dev_alloc(&ww.Gy, (size_t)ld));
@@ -185,12 +204,14 @@ int alloc_wstep(WstepWorkspace& ww, int64_t ld) {
     RBL_TRY(dev_alloc(&ww.p, (size_t)ld));
     RBL_TRY(dev_alloc(&ww.scal, 8));
     RBL_TRY(dev_alloc(&ww.flags, 8));
+    RBL_TRY(alloc_wstep_pin(ww));
     return RBL_OK;
 }
 
 void free_wstep(WstepWorkspace& ww) {
     dev_free(ww.yk); dev_free(ww.Gy); dev_free(ww.wn); dev_free(ww.r); dev_free(ww.p); dev_free(ww.scal);
     dev_free(ww.flags);
+    free_wstep_pin(ww);
     ww = WstepWorkspace{};
 }
 
@@ -331,7 +352,8 @@ int rbl_destroy(rbl_solver* h) {
     dev_free(h->z); dev_free(h->lam); dev_free(h->v); dev_free(h->m); dev_free(h->c);
     dev_free(h->sigma_a); dev_free(h->sigma_b); dev_free(h->slab); dev_free(h->partials);
     if (h->red_owned) dev_free(h->red);
-    dev_free(h->red2); dev_free(h->ysign); dev_free(h->colstats); dev_free(h->z_next); dev_free(h->p); dev_free(h->pred);
+    dev_free(h->red2); dev_free(h->ysign); dev_free(h->colstats); dev_free(h->z_next); dev_free(h->p); dev_free(h->p_alt); dev_free(h->pred);
+    if (h->hstat) (void)hipHostFree(h->hstat);
     free_sort(h->sw);
     free_pav(h->pw);
     dev_free(h->locx_a); dev_free(h->chunk_a); dev_free(h->cph_a); dev_free(h->cpl_a);
@@ -393,6 +415,11 @@ int rbl_create(const rbl_config* cfg, rbl_solver** out) {
     h->stream = h->own_stream;
     for (auto& e : h->ev) CKH(hipEventCreate(&e));
     for (auto& e : h->kev) CKH(hipEventCreate(&e));
+    {
+        void* hs = nullptr;
+        CKH(hipHostMalloc(&hs, 16 * sizeof(double), hipHostMallocDefault));
+        h->hstat = (double*)hs;
+    }
     {
         const int64_t n = h->n, ld = h->ld, nt = h->nt;
         void* Dp = nullptr;
@@ -465,6 +492,7 @@ int rbl_create(const rbl_config* cfg, rbl_solver** out) {
                 if (h->fused_ok) {
                     CK(dev_alloc(&h->z_next, (size_t)n));
                     CK(dev_alloc(&h->p, (size_t)ld));
+                    CK(dev_alloc(&h->p_alt, (size_t)ld));
                     CK(dev_alloc(&h->pred, 2));
                     size_t sb = (size_t)sweep_erm_blocks(h->num_cu) * ld * sizeof(double);
                     (void)sb;
@@ -813,15 +841,34 @@ int rbl_phase_w(rbl_solver* h) {
         h->p_valid = true;
     }
     int wstep = h->cfg.wstep;
+    // The lasso's active-set kernel reports its status through pinned memory; the statistics of
+    // the new w and the rho prediction are enqueued behind it before the host looks at the
+    // status, so the device works through them while the host waits.  Only when the kernel did
+    // not converge (FISTA then changes w again) are they enqueued a second time.
+    bool fs_pending = false;
     RBL_TRY(run_wstep(wstep, h->G, h->ld, h->q, h->step_rho, h->cfg.reg, h->smooth_t, h->L, h->cfg.w_tol, 100000, h->w,
-                      h->ww, &h->inner_iters, h->stream));
-    RBL_TRY(launch_diffnorm2(h->ld, h->w, h->w_prev, h->red2, h->stream));
-    RBL_TRY(launch_reg_terms(h->ld, h->w, h->red2 + 1, h->stream));
+                      h->ww, &h->inner_iters, h->stream, &fs_pending));
+    const bool predict = h->fused_ok && h->p_valid;
+    auto after_w = [&]() -> int {
+        if (predict) {
+            RBL_TRY(launch_symv(h->G, h->ld, h->w, h->ww.Gy, h->stream));
+            RBL_TRY(launch_predict_rho(h->ld, h->q, h->p, h->p_alt, h->w, h->w_prev, h->ww.Gy, q_zz(h), h->step_rho,
+                                       217.0 * (double)h->d, h->pred, h->red2, h->stream));
+        } else {
+            RBL_TRY(launch_w_stats(h->ld, h->w, h->w_prev, h->red2, h->stream));
+        }
+        return RBL_OK;
+    };
+    RBL_TRY(after_w());
+    if (fs_pending) {
+        bool fell_back = false;
+        RBL_TRY(finish_wstep_l1(h->G, h->ld, h->q, h->step_rho, h->cfg.reg, h->L, h->cfg.w_tol, 100000, h->w, h->ww,
+                                &h->inner_iters, h->stream, &fell_back));
+        if (fell_back) RBL_TRY(after_w());
+    }
     h->pred_valid = false;
-    if (h->fused_ok && h->p_valid) {
-        RBL_TRY(launch_symv(h->G, h->ld, h->w, h->ww.Gy, h->stream));
-        RBL_TRY(launch_predict_rho(h->ld, h->q, h->p, h->w, h->ww.Gy, q_zz(h), h->step_rho, 217.0 * (double)h->d,
-                                   h->pred, h->stream));
+    if (predict) {
+        std::swap(h->p, h->p_alt);   // the recurrence's output becomes D^T lambda of the next iteration
         // test hook: RBL_DEBUG_MISPREDICT_EVERY=N corrupts every N-th prediction so that the
         // verification + unfused recomputation path is exercised (tests/test_gpu_solver.py)
         static const int mis_every = [] {
@@ -872,21 +919,36 @@ int rbl_phase_dual(rbl_solver* h, int want_objective) {
     return RBL_OK;
 }
 
+// One thread gathers the iteration's scalars into the pinned host block: the host then needs a
+// single stream wait and no copies (each small device-to-host copy costs ~15 us of stream time).
+static __global__ void k_pack_stats(const double* __restrict__ red, const double* __restrict__ red2,
+                             const double* __restrict__ pred, const int* __restrict__ branch,
+                             const unsigned* __restrict__ counters, double* __restrict__ hstat) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    hstat[0] = red[0];
+    hstat[1] = red[1];
+    hstat[2] = red2[0];
+    hstat[3] = red2[1];
+    hstat[4] = red2[2];
+    hstat[5] = pred ? pred[0] : 0.0;
+    hstat[6] = pred ? pred[1] : 0.0;
+    hstat[7] = branch ? (double)branch[0] : -1.0;
+    hstat[8] = counters ? (double)counters[0] : 0.0;
+}
+
 int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
     RBL_ENTER(h);
     RBL_HIP(hipEventRecord(h->ev[5], h->stream));
-    double r[2], r2[3], pr[2] = {0.0, 0.0};
-    RBL_HIP(hipMemcpyAsync(r, h->red, sizeof(double) * 2, hipMemcpyDeviceToHost, h->stream));
-    RBL_HIP(hipMemcpyAsync(r2, h->red2, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
-    if (h->fused_ran) RBL_HIP(hipMemcpyAsync(pr, h->pred, sizeof(double) * 2, hipMemcpyDeviceToHost, h->stream));
-    int br = -1;
-    unsigned merges = 0;
-    if (h->sorted_path) {
-        if (h->cfg.weight_function == RBL_W_EHRM)
-            RBL_HIP(hipMemcpyAsync(&br, h->pw.branch, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        RBL_HIP(hipMemcpyAsync(&merges, h->pw.counters, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-    }
+    hipLaunchKernelGGL(k_pack_stats, dim3(1), dim3(64), 0, h->stream, h->red, h->red2,
+                       h->fused_ran ? h->pred : (const double*)nullptr,
+                       (h->sorted_path && h->cfg.weight_function == RBL_W_EHRM) ? h->pw.branch : (const int*)nullptr,
+                       h->sorted_path ? h->pw.counters : (const unsigned*)nullptr, h->hstat);
+    RBL_HIP(hipGetLastError());
     RBL_HIP(hipStreamSynchronize(h->stream));
+    const volatile double* hs = h->hstat;
+    const double r[2] = {hs[0], hs[1]}, r2[3] = {hs[2], hs[3], hs[4]}, pr[2] = {hs[5], hs[6]};
+    const int br = (int)hs[7];
+    const unsigned merges = (unsigned)hs[8];
     const double primal = std::sqrt(r[0] > 0.0 ? r[0] : 0.0);   // algorithms.py:135
     const double dual = std::sqrt(r2[0] > 0.0 ? r2[0] : 0.0);   // algorithms.py:136
     double objective = NAN;
@@ -1428,6 +1490,11 @@ int rbl_k_wstep(int wstep, int64_t d, const double* G, const double* q, double r
     ww.scal = sc.alloc<double>(8);
     ww.flags = sc.alloc<int>(8);
     SC_CHECK(ww.yk && ww.Gy && ww.wn && ww.r && ww.p && ww.scal && ww.flags);
+    RBL_TRY(alloc_wstep_pin(ww));
+    struct PinGuard {
+        WstepWorkspace& w;
+        ~PinGuard() { free_wstep_pin(w); }
+    } pin_guard{ww};
     double lam = 0.0;
     RBL_TRY(launch_power_iteration(dG, ld, ww.yk, ww.Gy, ww.scal, 100, &lam, sc.s));
     double L = 1.02 * lam;

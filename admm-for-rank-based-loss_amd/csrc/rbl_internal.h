@@ -145,13 +145,22 @@ struct WstepWorkspace {
     double* p;      // d (CG)
     double* scal;   // small device scalars: [0]=t, [1]=rr, ...
     int* flags;     // [0]=done, [1]=iters
+    int* pin;       // host-pinned, device-visible: [0..3] = status block of the active-set lasso kernel
+    hipEvent_t fs_done;
 };
 int launch_power_iteration(const double* G, int64_t d, double* tmp1, double* tmp2, double* scal, int iters,
                            double* lambda_host, hipStream_t s);
 // lasso / smoothed-l1 by FISTA with restart, ridge by CG; w is updated in place.
+// If fs_pending != NULL and the w-step is the lasso, only the active-set kernel is enqueued and
+// *fs_pending = true is returned: the caller may enqueue work that assumes success, then calls
+// finish_wstep_l1(), which waits for the kernel's status and runs FISTA when it did not converge
+// (*fell_back = true: w changed again, work enqueued in between must be redone).
 int run_wstep(int wstep, const double* G, int64_t d, const double* q, double rho, double reg, double smooth_t,
               double L, double tol, int max_inner, double* w, WstepWorkspace& ws, int* iters_host,
-              hipStream_t s);
+              hipStream_t s, bool* fs_pending = nullptr);
+int finish_wstep_l1(const double* G, int64_t d, const double* q, double rho, double reg, double L, double tol,
+                    int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s, bool* fell_back);
+int launch_w_stats(int64_t d, const double* w, const double* w_prev, double* out3, hipStream_t s);
 // lasso_fs.hip: exact active-set (feature-sign) lasso in one workgroup; out_dev = 4 ints
 int launch_lasso_fs(const double* G, int64_t ld, int64_t d, const double* q, double* w, double kappa, int* out_dev,
                     hipStream_t s);
@@ -166,8 +175,10 @@ int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld
                      double* lam, double* v, double* z_new, double sigma0, double rho, const double* pred_dev,
                      double* slab, double* partials, double* q, double* red, double* zz_out, int num_cu, hipStream_t s,
                      hipEvent_t main_done, int want_obj);
-int launch_predict_rho(int64_t ld, const double* q, double* p, const double* w, const double* Gw, const double* zz,
-                       double rho, double cap, double* pred, hipStream_t s);
+// rho_{k+1} prediction + the w statistics (||w - w_prev||^2, sum w^2, ||w||_1 -> wstats[0..2]); p_out != p
+int launch_predict_rho(int64_t ld, const double* q, const double* p, double* p_out, const double* w, const double* w_prev,
+                       const double* Gw, const double* zz, double rho, double cap, double* pred, double* wstats,
+                       hipStream_t s);
 int launch_sumsq(int64_t n, const double* x, double* partials, double* out, hipStream_t s);
 int launch_symv(const double* G, int64_t ld, const double* x, double* y, hipStream_t s);
 

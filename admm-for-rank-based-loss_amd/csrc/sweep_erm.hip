@@ -249,28 +249,36 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
     }
 }
 
-// q[j] = sum_b slab[b][j]  (same as sweep.hip's k_colreduce; kept local to this file)
-__global__ __launch_bounds__(1024) void k_colreduce2(const double* __restrict__ slab, int nb, long long ld,
-                                                       double* __restrict__ q) {
-    __shared__ double red[16][64];
+// Column sums of the nb slab rows in two steps: CR_SLICES x ceil(ld/64) blocks each fold their share
+// of the rows into part[slice][ld] (fixed order), k_finish_sweep adds the slices.
+constexpr int CR_SLICES = 8;
+__global__ __launch_bounds__(256) void k_colreduce2(const double* __restrict__ slab, int nb, long long ld,
+                                                      double* __restrict__ part) {
+    __shared__ double red[4][64];
     const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long long col = (long long)blockIdx.x * 64 + cx;
+    const int slice = blockIdx.y;
+    const int per = (nb + CR_SLICES - 1) / CR_SLICES;
+    const int b0 = slice * per, b1 = min(nb, b0 + per);
     double acc = 0.0;
     if (col < ld)
-        for (int b = g; b < nb; b += 16) acc += slab[(long long)b * ld + col];
+        for (int b = b0 + g; b < b1; b += 4) acc += slab[(long long)b * ld + col];
     red[g][cx] = acc;
     __syncthreads();
-    if (g == 0 && col < ld) {
-        double sacc = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) sacc += red[k][cx];
-        q[col] = sacc;
-    }
+    if (g == 0 && col < ld) part[(long long)slice * ld + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
-// red[0] = sum primal^2, red[1] = sum loss, zz_out[0] = sum z'^2
-__global__ __launch_bounds__(256) void k_sum3(const double* __restrict__ partials, int nb, double* __restrict__ red,
-                                               double* __restrict__ zz_out) {
+// q[j] = sum_slices part[slice][j];  red[0] = sum primal^2, red[1] = 0 (the loss sum comes from
+// k_loss_sum when wanted), zz_out[0] = sum z'^2
+__global__ __launch_bounds__(256) void k_finish_sweep(const double* __restrict__ part, long long ld,
+                                                       double* __restrict__ q, const double* __restrict__ partials,
+                                                       int nb, double* __restrict__ red, double* __restrict__ zz_out) {
+    for (long long j = threadIdx.x; j < ld; j += 256) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < CR_SLICES; ++k) s += part[(long long)k * ld + j];
+        q[j] = s;
+    }
     __shared__ double smem[3 * 4];
     double a[3] = {0.0, 0.0, 0.0};
     for (int b = threadIdx.x; b < nb; b += 256) {
@@ -286,22 +294,31 @@ __global__ __launch_bounds__(256) void k_sum3(const double* __restrict__ partial
     }
 }
 
-// Predict rho_{k+1} before the pass.  Gw = G w_{k+1} (k_symv), q = D^T(z + lambda/rho) summed over
-// ranks, p = D^T lambda (kept by the recurrence below), zz = ||z||^2:
-//   D^T z = q - p/rho ;  ||z - D w||^2 = zz - 2 (D^T z)'w + w'Gw ;  p <- p + rho (D^T z - G w)
+// After the w-step, before the pass: the dual residual / regulariser sums of the new w
+//   wstats[0] = ||w - w_prev||^2 (algorithms.py:136), wstats[1] = sum w^2, wstats[2] = ||w||_1 (objective.py:83-86)
+// and the prediction of rho_{k+1}.  Gw = G w_{k+1} (k_symv), q = D^T(z + lambda/rho) summed over
+// ranks, p = D^T lambda (kept by the recurrence below, written to p_out), zz = ||z||^2:
+//   D^T z = q - p/rho ;  ||z - D w||^2 = zz - 2 (D^T z)'w + w'Gw ;  p_out = p + rho (D^T z - G w)
 __global__ __launch_bounds__(1024) void k_predict_rho(long long ld, const double* __restrict__ q,
-                                                       double* __restrict__ p, const double* __restrict__ w,
+                                                       const double* __restrict__ p, double* __restrict__ p_out,
+                                                       const double* __restrict__ w, const double* __restrict__ w_prev,
                                                        const double* __restrict__ Gw, const double* __restrict__ zz,
-                                                       double rho, double cap, double* __restrict__ pred) {
-    __shared__ double smem[2 * 16];
-    double a[2] = {0.0, 0.0};
+                                                       double rho, double cap, double* __restrict__ pred,
+                                                       double* __restrict__ wstats) {
+    __shared__ double smem[5 * 16];
+    double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (long long j = threadIdx.x; j < ld; j += 1024) {
+        const double wj = w[j];
         const double dz = q[j] - p[j] / rho;
-        a[0] += dz * w[j];
-        a[1] += w[j] * Gw[j];
-        p[j] = p[j] + rho * (dz - Gw[j]);
+        a[0] += dz * wj;
+        a[1] += wj * Gw[j];
+        p_out[j] = p[j] + rho * (dz - Gw[j]);
+        const double t = wj - w_prev[j];
+        a[2] += t * t;
+        a[3] += wj * wj;
+        a[4] += fabs(wj);
     }
-    rbl::block_sum<2, 1024>(a, smem);
+    rbl::block_sum<5, 1024>(a, smem);
     if (threadIdx.x == 0) {
         double pr2 = zz[0] - 2.0 * a[0] + a[1];
         if (pr2 < 0.0) pr2 = 0.0;
@@ -310,6 +327,9 @@ __global__ __launch_bounds__(1024) void k_predict_rho(long long ld, const double
         if (rn > cap) rn = cap;
         pred[0] = rn;
         pred[1] = primal;
+        wstats[0] = a[2];
+        wstats[1] = a[3];
+        wstats[2] = a[4];
     }
 }
 
@@ -355,6 +375,7 @@ bool sweep_erm_supported(int storage, int64_t ld) {
 }
 
 int sweep_erm_blocks(int num_cu) { return num_cu * 2; }  // 2 blocks of 4 waves per CU (2 waves per SIMD)
+int sweep_erm_slab_rows(int num_cu) { return sweep_erm_blocks(num_cu) + CR_SLICES; }
 
 int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld, const double* w, const double* z_old,
                      double* lam, double* v, double* z_new, double sigma0, double rho, const double* pred_dev,
@@ -373,8 +394,10 @@ int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld
     }
     RBL_TRY(rc);
     if (main_done) RBL_HIP(hipEventRecord(main_done, s));
-    hipLaunchKernelGGL(k_colreduce2, dim3((unsigned)((ld + 63) / 64)), dim3(1024), 0, s, slab, grid, (long long)ld, q);
-    hipLaunchKernelGGL(k_sum3, dim3(1), dim3(256), 0, s, partials, grid, red, zz_out);
+    double* part = slab + (size_t)grid * ld;   // CR_SLICES rows behind the grid rows of the slab
+    hipLaunchKernelGGL(k_colreduce2, dim3((unsigned)((ld + 63) / 64), CR_SLICES), dim3(256), 0, s, slab, grid, (long long)ld,
+                       part);
+    hipLaunchKernelGGL(k_finish_sweep, dim3(1), dim3(256), 0, s, part, (long long)ld, q, partials, grid, red, zz_out);
     RBL_HIP(hipGetLastError());
     // objective.py:11-24: the per-sample losses are summed from v in a pass of their own (8 B per
     // row) - exp/log1p inside the sweep cost registers on its critical path
@@ -382,9 +405,11 @@ int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld
     return RBL_OK;
 }
 
-int launch_predict_rho(int64_t ld, const double* q, double* p, const double* w, const double* Gw, const double* zz,
-                       double rho, double cap, double* pred, hipStream_t s) {
-    hipLaunchKernelGGL(k_predict_rho, dim3(1), dim3(1024), 0, s, (long long)ld, q, p, w, Gw, zz, rho, cap, pred);
+int launch_predict_rho(int64_t ld, const double* q, const double* p, double* p_out, const double* w, const double* w_prev,
+                       const double* Gw, const double* zz, double rho, double cap, double* pred, double* wstats,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_predict_rho, dim3(1), dim3(1024), 0, s, (long long)ld, q, p, p_out, w, w_prev, Gw, zz, rho, cap,
+                       pred, wstats);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

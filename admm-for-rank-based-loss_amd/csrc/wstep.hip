@@ -243,6 +243,25 @@ __global__ __launch_bounds__(UPD_THREADS) void k_reg_terms(long long d, const do
     }
 }
 
+// out[0] = ||w - w_prev||^2 (algorithms.py:136), out[1] = sum w^2, out[2] = ||w||_1 (objective.py:83-86)
+__global__ __launch_bounds__(UPD_THREADS) void k_w_stats(long long d, const double* __restrict__ w,
+                                                          const double* __restrict__ w_prev, double* __restrict__ out) {
+    __shared__ double smem[3 * UPD_THREADS / 64];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (long long j = threadIdx.x; j < d; j += UPD_THREADS) {
+        const double t = w[j] - w_prev[j];
+        acc[0] += t * t;
+        acc[1] += w[j] * w[j];
+        acc[2] += fabs(w[j]);
+    }
+    rbl::block_sum<3, UPD_THREADS>(acc, smem);
+    if (threadIdx.x == 0) {
+        out[0] = acc[0];
+        out[1] = acc[1];
+        out[2] = acc[2];
+    }
+}
+
 __global__ void k_soft_threshold(long long d, double* __restrict__ w, double t) {
     // smoothADMMmethod's final step, src/optim/algorithms.py:258
     for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < d; j += (long long)gridDim.x * blockDim.x) {
@@ -274,17 +293,58 @@ int launch_power_iteration(const double* G, int64_t ld, double* x, double* y, do
     return RBL_OK;
 }
 
+namespace {
+
+// FISTA with gradient restart (lasso: mode 0, Huber-smoothed l1: mode 1), polled every BATCH iterations
+int run_fista(int mode, const double* G, int64_t ld, const double* q, double rho, double reg, double smooth_t, double L,
+              double tol, int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s) {
+    constexpr int BATCH = 8;
+    const unsigned sg = symv_grid(ld);
+    int hflags[2] = {0, 0};
+    FistaParams P;
+    P.mode = mode;
+    P.L = L;
+    P.kappa = reg / (2.0 * rho);
+    P.rho = rho;
+    P.reg = reg;
+    P.t = smooth_t;
+    P.tol = tol;
+    const double one = 1.0;
+    RBL_HIP(hipMemcpyAsync(ws.scal, &one, sizeof(double), hipMemcpyHostToDevice, s));
+    RBL_HIP(hipMemsetAsync(ws.flags, 0, 2 * sizeof(int), s));
+    RBL_HIP(hipMemcpyAsync(ws.yk, w, sizeof(double) * ld, hipMemcpyDeviceToDevice, s));
+    int done_iters = 0;
+    while (done_iters < max_inner) {
+        for (int b = 0; b < BATCH; ++b) {
+            hipLaunchKernelGGL(k_symv, dim3(sg), dim3(256), 0, s, G, (long long)ld, ws.yk, ws.Gy, 1.0, 0.0, ws.flags);
+            hipLaunchKernelGGL(k_fista_update, dim3(1), dim3(UPD_THREADS), 0, s, (long long)ld, ws.Gy, q, w, ws.yk, P,
+                               ws.scal, ws.flags);
+        }
+        done_iters += BATCH;
+        RBL_HIP(hipMemcpyAsync(hflags, ws.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        RBL_HIP(hipStreamSynchronize(s));
+        if (hflags[0]) break;
+    }
+    RBL_HIP(hipGetLastError());
+    if (iters_host) *iters_host = hflags[1];
+    return RBL_OK;
+}
+
+}  // namespace
+
 int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rho, double reg, double smooth_t,
-              double L, double tol, int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s) {
+              double L, double tol, int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s,
+              bool* fs_pending) {
+    if (fs_pending) *fs_pending = false;
     if (ld > (long long)UPD_THREADS * UPD_PER) {
         rbl_set_error("w-step: d=%lld exceeds the single-block update limit %d", (long long)ld, UPD_THREADS * UPD_PER);
         return RBL_ERR_INVALID;
     }
-    const unsigned sg = symv_grid(ld);
-    int hflags[2] = {0, 0};
-    constexpr int BATCH = 8;
     if (wstep == RBL_WSTEP_L2) {
         // (rho G + reg I) w = rho q
+        const unsigned sg = symv_grid(ld);
+        int hflags[2] = {0, 0};
+        constexpr int BATCH = 8;
         hipLaunchKernelGGL(k_symv, dim3(sg), dim3(256), 0, s, G, (long long)ld, w, ws.Gy, rho, reg, (const int*)nullptr);
         hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(UPD_THREADS), 0, s, (long long)ld, ws.Gy, q, rho, ws.r, ws.p, tol,
                            ws.scal, ws.flags);
@@ -300,47 +360,38 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
             RBL_HIP(hipStreamSynchronize(s));
             if (hflags[0]) break;
         }
-    } else {
-        if (wstep == RBL_WSTEP_L1) {
-            // exact active-set solve first (lasso_fs.hip); FISTA only when the support does not
-            // fit its capacity (e.g. the dense initial w of algorithms.py:42) or it hits its cap
-            int fs[4] = {1, 0, 0, 0};
-            RBL_TRY(launch_lasso_fs(G, ld, ld, q, w, reg / (2.0 * rho), ws.flags + 4, s));
-            RBL_HIP(hipMemcpyAsync(fs, ws.flags + 4, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-            RBL_HIP(hipStreamSynchronize(s));
-            if (fs[0] == 0) {
-                if (iters_host) *iters_host = fs[1];
-                return RBL_OK;
-            }
-        }
-        FistaParams P;
-        P.mode = (wstep == RBL_WSTEP_L1) ? 0 : 1;
-        P.L = L;
-        P.kappa = reg / (2.0 * rho);
-        P.rho = rho;
-        P.reg = reg;
-        P.t = smooth_t;
-        P.tol = tol;
-        const double one = 1.0;
-        RBL_HIP(hipMemcpyAsync(ws.scal, &one, sizeof(double), hipMemcpyHostToDevice, s));
-        RBL_HIP(hipMemsetAsync(ws.flags, 0, 2 * sizeof(int), s));
-        RBL_HIP(hipMemcpyAsync(ws.yk, w, sizeof(double) * ld, hipMemcpyDeviceToDevice, s));
-        int done_iters = 0;
-        while (done_iters < max_inner) {
-            for (int b = 0; b < BATCH; ++b) {
-                hipLaunchKernelGGL(k_symv, dim3(sg), dim3(256), 0, s, G, (long long)ld, ws.yk, ws.Gy, 1.0, 0.0, ws.flags);
-                hipLaunchKernelGGL(k_fista_update, dim3(1), dim3(UPD_THREADS), 0, s, (long long)ld, ws.Gy, q, w, ws.yk,
-                                   P, ws.scal, ws.flags);
-            }
-            done_iters += BATCH;
-            RBL_HIP(hipMemcpyAsync(hflags, ws.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-            RBL_HIP(hipStreamSynchronize(s));
-            if (hflags[0]) break;
-        }
+        RBL_HIP(hipGetLastError());
+        if (iters_host) *iters_host = hflags[1];
+        return RBL_OK;
     }
-    RBL_HIP(hipGetLastError());
-    if (iters_host) *iters_host = hflags[1];
-    return RBL_OK;
+    if (wstep == RBL_WSTEP_L1) {
+        // exact active-set solve first (lasso_fs.hip); FISTA only when the support does not fit
+        // its capacity (e.g. the dense initial w of algorithms.py:42) or it hits its cap.  The
+        // kernel writes its status block straight into pinned host memory.
+        ws.pin[0] = 1;
+        RBL_TRY(launch_lasso_fs(G, ld, ld, q, w, reg / (2.0 * rho), ws.pin, s));
+        RBL_HIP(hipEventRecord(ws.fs_done, s));
+        if (fs_pending) {
+            *fs_pending = true;
+            return RBL_OK;
+        }
+        bool fell_back = false;
+        return finish_wstep_l1(G, ld, q, rho, reg, L, tol, max_inner, w, ws, iters_host, s, &fell_back);
+    }
+    return run_fista(1, G, ld, q, rho, reg, smooth_t, L, tol, max_inner, w, ws, iters_host, s);
+}
+
+int finish_wstep_l1(const double* G, int64_t ld, const double* q, double rho, double reg, double L, double tol,
+                    int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s, bool* fell_back) {
+    RBL_HIP(hipEventSynchronize(ws.fs_done));
+    const volatile int* st = ws.pin;
+    if (st[0] == 0) {
+        if (iters_host) *iters_host = st[1];
+        if (fell_back) *fell_back = false;
+        return RBL_OK;
+    }
+    if (fell_back) *fell_back = true;
+    return run_fista(0, G, ld, q, rho, reg, 1.0, L, tol, max_inner, w, ws, iters_host, s);
 }
 
 int launch_symv(const double* G, int64_t ld, const double* x, double* y, hipStream_t s) {
@@ -357,6 +408,12 @@ int launch_diffnorm2(int64_t d, const double* a, const double* b, double* out, h
 
 int launch_reg_terms(int64_t d, const double* w, double* out2, hipStream_t s) {
     hipLaunchKernelGGL(k_reg_terms, dim3(1), dim3(UPD_THREADS), 0, s, (long long)d, w, out2);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_w_stats(int64_t d, const double* w, const double* w_prev, double* out3, hipStream_t s) {
+    hipLaunchKernelGGL(k_w_stats, dim3(1), dim3(UPD_THREADS), 0, s, (long long)d, w, w_prev, out3);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }
