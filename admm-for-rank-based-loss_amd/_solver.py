@@ -263,7 +263,9 @@ class Solver:
 
     # -------------------------------------------------------------- measurement
     def profile_kernels(self, enable=True):
-        _lib.check(self.lib.rbl_profile_kernels(self._h, 1 if enable else 0))
+        """0/False: no events in the iteration; 1/True: HIP events around the sweep kernels
+        (kernel_time()); 2: also around the phases (the ms_* fields of the step statistics)."""
+        _lib.check(self.lib.rbl_profile_kernels(self._h, int(enable)))
 
     def reset_kernel_times(self):
         _lib.check(self.lib.rbl_reset_kernel_times(self._h))

@@ -77,8 +77,29 @@ struct rbl_solver {
     int pending_mask = 0;  // bit 0: the q part, bit 1: the residual part of the exchange buffer awaits a sum over ranks
     double *z_next = nullptr, *p = nullptr, *p_alt = nullptr, *pred = nullptr;
     double* hstat = nullptr;   // pinned host block the end-of-iteration statistics are packed into by the device
+    // The lasso w-step of iteration k+1 is enqueued by rbl_phase_finish(k) before the host has
+    // read iteration k's statistics (its inputs q and rho_{k+1} = pred[0] are already on the
+    // device); spec_w says that w currently holds that speculative w_{k+1} (w_prev = w_k).
+    bool spec_w = false, spec_timed = false;
+    hipEvent_t ev_spec[2] = {nullptr, nullptr};
+    bool phase_timing = false;   // rbl_profile_kernels level 2: HIP events around the phases (ms_* of rbl_stats)
     int64_t n_fused = 0, n_mispred = 0;
 };
+
+void rbl_spin_wait(const volatile int* word, int sentinel, hipStream_t stream) {
+    // No event behind the kernel: an event record costs ~5 us of stream time on this device and
+    // the iteration has none left in its steady state.  A launch that failed never writes the
+    // word, so after a generous spin the stream itself is waited for (then the word is final).
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned i = 1;; ++i) {
+        if (*word != sentinel) return;
+        if ((i & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            (void)hipStreamSynchronize(stream);
+            return;
+        }
+        __builtin_ia32_pause();
+    }
+}
 
 namespace {
 
@@ -182,18 +203,15 @@ int alloc_prefix(double** locx, double** chunk, double** cph, double** cpl, int6
 // event marks its completion: the host reads the status without a copy or a stream-wide wait
 int alloc_wstep_pin(WstepWorkspace& ww) {
     void* pin = nullptr;
-    RBL_HIP(hipHostMalloc(&pin, 64, hipHostMallocDefault));
+    RBL_HIP(hipHostMalloc(&pin, 64, hipHostMallocCoherent));
     ww.pin = (int*)pin;
     for (int i = 0; i < 16; ++i) ww.pin[i] = 0;
-    RBL_HIP(hipEventCreateWithFlags(&ww.fs_done, hipEventDisableTiming));
     return RBL_OK;
 }
 
 void free_wstep_pin(WstepWorkspace& ww) {
     if (ww.pin) (void)hipHostFree(ww.pin);
-    if (ww.fs_done) (void)hipEventDestroy(ww.fs_done);
     ww.pin = nullptr;
-    ww.fs_done = nullptr;
 }
 
 int alloc_wstep(WstepWorkspace& ww, int64_t ld) {
@@ -361,6 +379,7 @@ int rbl_destroy(rbl_solver* h) {
     free_wstep(h->ww);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : h->kev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : h->ev_spec) if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return RBL_OK;
@@ -415,9 +434,10 @@ int rbl_create(const rbl_config* cfg, rbl_solver** out) {
     h->stream = h->own_stream;
     for (auto& e : h->ev) CKH(hipEventCreate(&e));
     for (auto& e : h->kev) CKH(hipEventCreate(&e));
+    for (auto& e : h->ev_spec) CKH(hipEventCreate(&e));
     {
         void* hs = nullptr;
-        CKH(hipHostMalloc(&hs, 16 * sizeof(double), hipHostMallocDefault));
+        CKH(hipHostMalloc(&hs, 16 * sizeof(double), hipHostMallocCoherent));
         h->hstat = (double*)hs;
     }
     {
@@ -512,13 +532,33 @@ fail:
     return rc;
 }
 
-#define RBL_ENTER(h)                                   \
+// Entry of the functions that advance the iteration (phases, step, solve) or only read handle
+// bookkeeping: a speculative w-step in flight stays.
+#define RBL_ENTER_ITER(h)                              \
     do {                                               \
         if (!(h)) {                                    \
             rbl_set_error("solver handle is NULL");    \
             return RBL_ERR_INVALID;                    \
         }                                              \
         RBL_HIP(hipSetDevice((h)->cfg.device));        \
+    } while (0)
+
+// w_{k+1} was computed ahead of time (rbl_phase_finish); anything that looks at or replaces the
+// state between two iterations must see w_k: put it back (the w-step is simply redone later).
+int cancel_spec(rbl_solver* h) {
+    if (!h->spec_w) return RBL_OK;
+    h->spec_w = false;
+    h->spec_timed = false;
+    RBL_HIP(hipMemcpyAsync(h->w, h->w_prev, sizeof(double) * h->ld, hipMemcpyDeviceToDevice, h->stream));
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    return RBL_OK;
+}
+
+// Entry of every other function of the API
+#define RBL_ENTER(h)              \
+    do {                          \
+        RBL_ENTER_ITER(h);        \
+        RBL_TRY(cancel_spec(h));  \
     } while (0)
 
 int rbl_set_stream(rbl_solver* h, void* hip_stream) {
@@ -705,9 +745,10 @@ int rbl_get_D(rbl_solver* h, double* out) {
 }
 
 int rbl_get_state(rbl_solver* h, double* w, double* z, double* lam, double* rho, int64_t* iter, double* smooth_t) {
-    RBL_ENTER(h);
+    RBL_ENTER_ITER(h);
     RBL_HIP(hipStreamSynchronize(h->stream));
-    if (w) RBL_HIP(hipMemcpy(w, h->w, sizeof(double) * h->d, hipMemcpyDeviceToHost));
+    // while the next w-step is in flight ahead of time, the current iterate w_k is w_prev
+    if (w) RBL_HIP(hipMemcpy(w, h->spec_w ? h->w_prev : h->w, sizeof(double) * h->d, hipMemcpyDeviceToHost));
     if (z && h->z) RBL_HIP(hipMemcpy(z, h->z, sizeof(double) * h->n, hipMemcpyDeviceToHost));
     if (lam && h->lam) RBL_HIP(hipMemcpy(lam, h->lam, sizeof(double) * h->n, hipMemcpyDeviceToHost));
     if (rho) *rho = h->rho;
@@ -780,10 +821,10 @@ static inline double* q_pinit(rbl_solver* h) { return h->q + h->ld; }      // D^
 static inline double* q_zz(rbl_solver* h) { return h->q + 2 * h->ld; }     // ||z||^2 of the current z
 
 int rbl_phase_m(rbl_solver* h) {
-    RBL_ENTER(h);
+    RBL_ENTER_ITER(h);
     RBL_TRY(require_ready(h));
     h->step_rho = h->rho;
-    RBL_HIP(hipEventRecord(h->ev[0], h->stream));
+    if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[0], h->stream));
     if (h->fused_ok && h->z_ready) return RBL_OK;
     RBL_TRY(ensure_v(h));
     if (h->sorted_path) RBL_TRY(launch_make_m(h->n, h->step_rho, h->v, h->lam, h->m, h->stream));
@@ -791,7 +832,7 @@ int rbl_phase_m(rbl_solver* h) {
 }
 
 int rbl_phase_z(rbl_solver* h, const void* m_all_dev) {
-    RBL_ENTER(h);
+    RBL_ENTER_ITER(h);
     const double rho = h->step_rho;
     if (h->fused_ok && h->z_ready) {
         std::swap(h->z, h->z_next);  // the z-step of this iteration was done by the previous pass
@@ -809,12 +850,12 @@ int rbl_phase_z(rbl_solver* h, const void* m_all_dev) {
         }
         RBL_TRY(z_step_sorted(h, msrc, rho));
     }
-    RBL_HIP(hipEventRecord(h->ev[1], h->stream));
+    if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[1], h->stream));
     return RBL_OK;
 }
 
 int rbl_phase_q(rbl_solver* h) {
-    RBL_ENTER(h);
+    RBL_ENTER_ITER(h);
     if (!(h->fused_ok && h->z_ready)) {
         if (h->profile) RBL_HIP(hipEventRecord(h->kev[2], h->stream));
         RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream,
@@ -828,26 +869,30 @@ int rbl_phase_q(rbl_solver* h) {
     }
     h->pending_mask = (h->fused_ok && h->z_ready) ? 0 : 1;  // a fused pass' q was already summed with its residuals
     h->z_ready = false;  // consumed: q (and zz) now belong to the iteration in flight
-    RBL_HIP(hipEventRecord(h->ev[2], h->stream));
+    if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[2], h->stream));
     return RBL_OK;
 }
 
 int rbl_phase_w(rbl_solver* h) {
-    RBL_ENTER(h);
-    RBL_HIP(hipMemcpyAsync(h->w_prev, h->w, sizeof(double) * h->ld, hipMemcpyDeviceToDevice, h->stream));
+    RBL_ENTER_ITER(h);
+    const bool spec = h->spec_w;   // this w-step (and what follows it) was enqueued by the previous rbl_phase_finish
+    h->spec_w = false;
+    int wstep = h->cfg.wstep;
+    if (!spec && wstep != RBL_WSTEP_L1)   // the lasso kernel saves its warm start itself
+        RBL_HIP(hipMemcpyAsync(h->w_prev, h->w, sizeof(double) * h->ld, hipMemcpyDeviceToDevice, h->stream));
     if (h->p_pending) {
         RBL_HIP(hipMemcpyAsync(h->p, q_pinit(h), sizeof(double) * h->ld, hipMemcpyDeviceToDevice, h->stream));
         h->p_pending = false;
         h->p_valid = true;
     }
-    int wstep = h->cfg.wstep;
     // The lasso's active-set kernel reports its status through pinned memory; the statistics of
     // the new w and the rho prediction are enqueued behind it before the host looks at the
     // status, so the device works through them while the host waits.  Only when the kernel did
     // not converge (FISTA then changes w again) are they enqueued a second time.
-    bool fs_pending = false;
-    RBL_TRY(run_wstep(wstep, h->G, h->ld, h->q, h->step_rho, h->cfg.reg, h->smooth_t, h->L, h->cfg.w_tol, 100000, h->w,
-                      h->ww, &h->inner_iters, h->stream, &fs_pending));
+    bool fs_pending = spec;
+    if (!spec)
+        RBL_TRY(run_wstep(wstep, h->G, h->ld, h->q, h->step_rho, h->cfg.reg, h->smooth_t, h->L, h->cfg.w_tol, 100000,
+                          h->w, h->ww, &h->inner_iters, h->stream, &fs_pending, nullptr, h->w_prev));
     const bool predict = h->fused_ok && h->p_valid;
     auto after_w = [&]() -> int {
         if (predict) {
@@ -859,7 +904,7 @@ int rbl_phase_w(rbl_solver* h) {
         }
         return RBL_OK;
     };
-    RBL_TRY(after_w());
+    if (!spec) RBL_TRY(after_w());
     if (fs_pending) {
         bool fell_back = false;
         RBL_TRY(finish_wstep_l1(h->G, h->ld, h->q, h->step_rho, h->cfg.reg, h->L, h->cfg.w_tol, 100000, h->w, h->ww,
@@ -882,12 +927,13 @@ int rbl_phase_w(rbl_solver* h) {
         }
         h->pred_valid = true;
     }
-    RBL_HIP(hipEventRecord(h->ev[3], h->stream));
+    if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[3], h->stream));
     return RBL_OK;
 }
 
 int rbl_phase_dual(rbl_solver* h, int want_objective) {
-    RBL_ENTER(h);
+    RBL_ENTER_ITER(h);
+
     h->fused_ran = false;
     if (h->fused_ok && h->pred_valid) {
         if (h->profile) RBL_HIP(hipEventRecord(h->kev[4], h->stream));
@@ -897,7 +943,7 @@ int rbl_phase_dual(rbl_solver* h, int want_objective) {
         if (h->profile) h->kev_pending[2] = h->n > 0;
         h->fused_ran = true;
         h->v_valid = true;
-        RBL_HIP(hipEventRecord(h->ev[4], h->stream));
+        if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[4], h->stream));
     } else {
         if (h->profile) RBL_HIP(hipEventRecord(h->kev[0], h->stream));
         RBL_TRY(launch_gemv(h->storage, h->D, h->n, h->ld, h->w, h->v, h->num_cu, h->stream));
@@ -906,7 +952,7 @@ int rbl_phase_dual(rbl_solver* h, int want_objective) {
             h->kev_pending[0] = true;
         }
         h->v_valid = true;
-        RBL_HIP(hipEventRecord(h->ev[4], h->stream));
+        if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[4], h->stream));
         RBL_TRY(launch_dual(h->cfg.loss, h->n, h->step_rho, h->z, h->v, h->lam, h->partials, h->red, h->stream));
     }
     h->pending_mask = 2 | (h->fused_ran ? 1 : 0);
@@ -923,7 +969,7 @@ int rbl_phase_dual(rbl_solver* h, int want_objective) {
 // single stream wait and no copies (each small device-to-host copy costs ~15 us of stream time).
 static __global__ void k_pack_stats(const double* __restrict__ red, const double* __restrict__ red2,
                              const double* __restrict__ pred, const int* __restrict__ branch,
-                             const unsigned* __restrict__ counters, double* __restrict__ hstat) {
+                             const unsigned* __restrict__ counters, double* __restrict__ hstat, int seq) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     hstat[0] = red[0];
     hstat[1] = red[1];
@@ -934,17 +980,49 @@ static __global__ void k_pack_stats(const double* __restrict__ red, const double
     hstat[6] = pred ? pred[1] : 0.0;
     hstat[7] = branch ? (double)branch[0] : -1.0;
     hstat[8] = counters ? (double)counters[0] : 0.0;
+    __threadfence_system();
+    reinterpret_cast<volatile int*>(hstat + 15)[0] = seq;   // written last: the host polls this word
 }
 
 int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
-    RBL_ENTER(h);
-    RBL_HIP(hipEventRecord(h->ev[5], h->stream));
+    RBL_ENTER_ITER(h);
+    float spec_ms = 0.f;   // the w-step of THIS iteration ran before its ev[0]: add its time back
+    if (h->spec_timed) (void)hipEventElapsedTime(&spec_ms, h->ev_spec[0], h->ev_spec[1]);
+    h->spec_timed = false;
+    if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[5], h->stream));
+    volatile int* seq_word = reinterpret_cast<volatile int*>(h->hstat + 15);
+    const int pack_seq = (int)((h->iter & 0x3fffffff) + 1);
+    *seq_word = 0;
     hipLaunchKernelGGL(k_pack_stats, dim3(1), dim3(64), 0, h->stream, h->red, h->red2,
                        h->fused_ran ? h->pred : (const double*)nullptr,
                        (h->sorted_path && h->cfg.weight_function == RBL_W_EHRM) ? h->pw.branch : (const int*)nullptr,
-                       h->sorted_path ? h->pw.counters : (const unsigned*)nullptr, h->hstat);
+                       h->sorted_path ? h->pw.counters : (const unsigned*)nullptr, h->hstat, pack_seq);
     RBL_HIP(hipGetLastError());
-    RBL_HIP(hipStreamSynchronize(h->stream));
+    // Single-sweep lasso iterations: everything the next w-step needs is on the device already
+    // (q from the pass, rho_{k+1} = pred[0]), so it is enqueued now and runs while the host waits
+    // for and digests this iteration's statistics.  If they say "converged" or "rho was
+    // mispredicted", w is put back from w_prev below.
+    static const bool no_spec = [] {
+        const char* e = getenv("RBL_NO_SPECULATE");
+        return e && e[0] == '1';
+    }();
+    const bool try_spec = h->fused_ran && h->p_valid && h->cfg.wstep == RBL_WSTEP_L1 && !no_spec;
+    if (try_spec) {
+        if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev_spec[0], h->stream));
+        bool fs_pending = false;
+        RBL_TRY(run_wstep(RBL_WSTEP_L1, h->G, h->ld, h->q, 1.0, h->cfg.reg, h->smooth_t, h->L, h->cfg.w_tol, 100000, h->w,
+                          h->ww, nullptr, h->stream, &fs_pending, h->pred, h->w_prev));
+        RBL_TRY(launch_symv(h->G, h->ld, h->w, h->ww.Gy, h->stream));
+        RBL_TRY(launch_predict_rho(h->ld, h->q, h->p, h->p_alt, h->w, h->w_prev, h->ww.Gy, q_zz(h), 0.0,
+                                   217.0 * (double)h->d, h->pred, h->red2, h->stream, h->pred));
+        if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev_spec[1], h->stream));
+    }
+    rbl_spin_wait(seq_word, 0, h->stream);
+    if (*seq_word != pack_seq) {
+        rbl_set_error("phase_finish: the statistics kernel did not complete");
+        (void)hipGetLastError();
+        return RBL_ERR_HIP;
+    }
     const volatile double* hs = h->hstat;
     const double r[2] = {hs[0], hs[1]}, r2[3] = {hs[2], hs[3], hs[4]}, pr[2] = {hs[5], hs[6]};
     const int br = (int)hs[7];
@@ -987,12 +1065,24 @@ int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
         h->n_mispred += mispred;
     }
     h->pred_valid = false;
+    if (try_spec) {
+        if (!conv && h->z_ready) {
+            h->spec_w = true;
+            h->spec_timed = h->phase_timing;
+        } else {
+            RBL_HIP(hipMemcpyAsync(h->w, h->w_prev, sizeof(double) * h->ld, hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
     float ms[5] = {0, 0, 0, 0, 0};
-    (void)hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]);
-    (void)hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]);
-    (void)hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]);
-    (void)hipEventElapsedTime(&ms[3], h->ev[3], h->ev[4]);
-    (void)hipEventElapsedTime(&ms[4], h->ev[0], h->ev[5]);
+    if (h->phase_timing) {
+        (void)hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]);
+        (void)hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]);
+        (void)hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]);
+        (void)hipEventElapsedTime(&ms[3], h->ev[3], h->ev[4]);
+        (void)hipEventElapsedTime(&ms[4], h->ev[0], h->ev[5]);
+        ms[2] += spec_ms;
+        ms[4] += spec_ms;
+    }
     for (int k = 0; k < 3; ++k) {
         if (h->kev_pending[k]) {
             float t = 0.f;
@@ -1029,7 +1119,7 @@ int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
 }
 
 int rbl_step(rbl_solver* h, int want_objective, rbl_stats* out) {
-    RBL_ENTER(h);
+    RBL_ENTER_ITER(h);
     if (h->nt != h->n) {
         rbl_set_error("rbl_step: sharded problem - drive the phase API with collectives in between");
         return RBL_ERR_STATE;
@@ -1062,6 +1152,7 @@ int rbl_solve(rbl_solver* h, int max_iter, int want_objective, rbl_stats* last, 
         }
         if (st.converged) break;
     }
+    RBL_TRY(cancel_spec(h));   // a solve ends on w_k, not on the w-step enqueued ahead of iteration k+1
     if (last) *last = st;
     return RBL_OK;
 }
@@ -1171,6 +1262,8 @@ int rbl_reset_kernel_times(rbl_solver* h) {
 int rbl_profile_kernels(rbl_solver* h, int enable) {
     RBL_ENTER(h);
     h->profile = enable != 0;
+    h->phase_timing = enable >= 2;
+    RBL_HIP(hipStreamSynchronize(h->stream));
     return RBL_OK;
 }
 

@@ -99,11 +99,18 @@ __device__ inline void chol_solve(FsShared& S, int na, double* b, double* xo) {
 // iterations, out[2] = inner (feature-sign) steps, out[3] = final support size
 __global__ __launch_bounds__(FS_THREADS) void k_lasso_fs(const double* __restrict__ G, long long ld, long long d,
                                                           const double* __restrict__ q, double* __restrict__ w,
-                                                          double kappa, int max_steps, int* __restrict__ out) {
+                                                          double kappa_val, const double* __restrict__ rho_dev,
+                                                          double reg, double* __restrict__ w_prev_out, int max_steps,
+                                                          int* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char fs_raw[];
     FsShared& S = *reinterpret_cast<FsShared*>(fs_raw);
     const int tid = threadIdx.x;
     const int nd = (int)d;
+    // kappa = reg / (2 rho) with rho read on the device when the launch was enqueued before the
+    // host knew it (the w-step of the next iteration, api.hip: rbl_phase_finish)
+    const double kappa = rho_dev ? reg / (2.0 * rho_dev[0]) : kappa_val;
+    if (w_prev_out)   // the warm start is the previous iterate: keep it for the dual residual
+        for (long long j = tid; j < ld; j += FS_THREADS) w_prev_out[j] = w[j];
 
     // ---- initial active set = support of the warm start, in index order (deterministic)
     const int per = (nd + FS_THREADS - 1) / FS_THREADS;
@@ -128,10 +135,11 @@ __global__ __launch_bounds__(FS_THREADS) void k_lasso_fs(const double* __restric
     int status = 0, outer = 0, steps = 0;
     if (na > FS_MAX) {
         if (tid == 0) {
-            out[0] = 1;
             out[1] = 0;
             out[2] = 0;
             out[3] = na;
+            __threadfence_system();
+            out[0] = 1;   // written last: the host polls this word (pinned memory)
         }
         return;
     }
@@ -327,10 +335,11 @@ __global__ __launch_bounds__(FS_THREADS) void k_lasso_fs(const double* __restric
     __syncthreads();
     for (int a = tid; a < na; a += FS_THREADS) w[S.A[a]] = S.wA[a];
     if (tid == 0) {
-        out[0] = status;
         out[1] = outer;
         out[2] = steps;
         out[3] = na;
+        __threadfence_system();
+        out[0] = status;   // written last: the host polls this word (pinned memory)
     }
 }
 
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_lasso_fs(const double* __restric
 size_t lasso_fs_lds_bytes() { return sizeof(FsShared); }
 
 int launch_lasso_fs(const double* G, int64_t ld, int64_t d, const double* q, double* w, double kappa, int* out_dev,
-                    hipStream_t s) {
+                    hipStream_t s, const double* rho_dev, double reg, double* w_prev_out) {
     if (d > FS_MAXD) {
         rbl_set_error("lasso_fs: d too large");
         return RBL_ERR_INVALID;
@@ -351,7 +360,7 @@ int launch_lasso_fs(const double* G, int64_t ld, int64_t d, const double* q, dou
         attr_set = true;
     }
     hipLaunchKernelGGL(k_lasso_fs, dim3(1), dim3(FS_THREADS), sizeof(FsShared), s, G, (long long)ld, (long long)d, q, w,
-                       kappa, 6 * FS_MAX + 64, out_dev);
+                       kappa, rho_dev, reg, w_prev_out, 6 * FS_MAX + 64, out_dev);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

@@ -7,6 +7,11 @@
 
 void rbl_set_error(const char* fmt, ...);
 
+// Host wait for a word in pinned memory that a kernel writes last (after __threadfence_system):
+// spins on the word; after 2 s without a change the stream is waited for instead, so that a
+// failed launch cannot hang the host.
+void rbl_spin_wait(const volatile int* word, int sentinel, hipStream_t stream);
+
 #define RBL_HIP(x)                                                                         \
     do {                                                                                   \
         hipError_t e_ = (x);                                                               \
@@ -146,7 +151,6 @@ struct WstepWorkspace {
     double* scal;   // small device scalars: [0]=t, [1]=rr, ...
     int* flags;     // [0]=done, [1]=iters
     int* pin;       // host-pinned, device-visible: [0..3] = status block of the active-set lasso kernel
-    hipEvent_t fs_done;
 };
 int launch_power_iteration(const double* G, int64_t d, double* tmp1, double* tmp2, double* scal, int iters,
                            double* lambda_host, hipStream_t s);
@@ -157,13 +161,15 @@ int launch_power_iteration(const double* G, int64_t d, double* tmp1, double* tmp
 // (*fell_back = true: w changed again, work enqueued in between must be redone).
 int run_wstep(int wstep, const double* G, int64_t d, const double* q, double rho, double reg, double smooth_t,
               double L, double tol, int max_inner, double* w, WstepWorkspace& ws, int* iters_host,
-              hipStream_t s, bool* fs_pending = nullptr);
+              hipStream_t s, bool* fs_pending = nullptr, const double* rho_dev = nullptr,
+              double* w_prev_out = nullptr);
 int finish_wstep_l1(const double* G, int64_t d, const double* q, double rho, double reg, double L, double tol,
                     int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s, bool* fell_back);
 int launch_w_stats(int64_t d, const double* w, const double* w_prev, double* out3, hipStream_t s);
 // lasso_fs.hip: exact active-set (feature-sign) lasso in one workgroup; out_dev = 4 ints
+// rho_dev != NULL: kappa = reg / (2 rho_dev[0]) is formed on the device; w_prev_out != NULL: the warm start is saved there
 int launch_lasso_fs(const double* G, int64_t ld, int64_t d, const double* q, double* w, double kappa, int* out_dev,
-                    hipStream_t s);
+                    hipStream_t s, const double* rho_dev = nullptr, double reg = 0.0, double* w_prev_out = nullptr);
 int launch_diffnorm2(int64_t d, const double* a, const double* b, double* out, hipStream_t s);
 int launch_reg_terms(int64_t d, const double* w, double* out2 /* [sum w^2, sum |w|] */, hipStream_t s);
 int launch_soft_threshold(int64_t d, double* w, double t, hipStream_t s);
@@ -176,9 +182,10 @@ int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld
                      double* slab, double* partials, double* q, double* red, double* zz_out, int num_cu, hipStream_t s,
                      hipEvent_t main_done, int want_obj);
 // rho_{k+1} prediction + the w statistics (||w - w_prev||^2, sum w^2, ||w||_1 -> wstats[0..2]); p_out != p
+// rho_dev != NULL: rho is read from rho_dev[0] on the device (may alias pred)
 int launch_predict_rho(int64_t ld, const double* q, const double* p, double* p_out, const double* w, const double* w_prev,
                        const double* Gw, const double* zz, double rho, double cap, double* pred, double* wstats,
-                       hipStream_t s);
+                       hipStream_t s, const double* rho_dev = nullptr);
 int launch_sumsq(int64_t n, const double* x, double* partials, double* out, hipStream_t s);
 int launch_symv(const double* G, int64_t ld, const double* x, double* y, hipStream_t s);
 

@@ -303,9 +303,10 @@ __global__ __launch_bounds__(1024) void k_predict_rho(long long ld, const double
                                                        const double* __restrict__ p, double* __restrict__ p_out,
                                                        const double* __restrict__ w, const double* __restrict__ w_prev,
                                                        const double* __restrict__ Gw, const double* __restrict__ zz,
-                                                       double rho, double cap, double* __restrict__ pred,
-                                                       double* __restrict__ wstats) {
+                                                       double rho_val, const double* rho_dev, double cap,
+                                                       double* pred, double* __restrict__ wstats) {
     __shared__ double smem[5 * 16];
+    const double rho = rho_dev ? rho_dev[0] : rho_val;   // rho_dev may alias pred: read before the barrier below
     double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (long long j = threadIdx.x; j < ld; j += 1024) {
         const double wj = w[j];
@@ -407,9 +408,9 @@ int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld
 
 int launch_predict_rho(int64_t ld, const double* q, const double* p, double* p_out, const double* w, const double* w_prev,
                        const double* Gw, const double* zz, double rho, double cap, double* pred, double* wstats,
-                       hipStream_t s) {
-    hipLaunchKernelGGL(k_predict_rho, dim3(1), dim3(1024), 0, s, (long long)ld, q, p, p_out, w, w_prev, Gw, zz, rho, cap,
-                       pred, wstats);
+                       hipStream_t s, const double* rho_dev) {
+    hipLaunchKernelGGL(k_predict_rho, dim3(1), dim3(1024), 0, s, (long long)ld, q, p, p_out, w, w_prev, Gw, zz, rho, rho_dev,
+                       cap, pred, wstats);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

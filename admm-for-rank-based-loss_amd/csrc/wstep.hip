@@ -334,7 +334,7 @@ int run_fista(int mode, const double* G, int64_t ld, const double* q, double rho
 
 int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rho, double reg, double smooth_t,
               double L, double tol, int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s,
-              bool* fs_pending) {
+              bool* fs_pending, const double* rho_dev, double* w_prev_out) {
     if (fs_pending) *fs_pending = false;
     if (ld > (long long)UPD_THREADS * UPD_PER) {
         rbl_set_error("w-step: d=%lld exceeds the single-block update limit %d", (long long)ld, UPD_THREADS * UPD_PER);
@@ -368,9 +368,8 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
         // exact active-set solve first (lasso_fs.hip); FISTA only when the support does not fit
         // its capacity (e.g. the dense initial w of algorithms.py:42) or it hits its cap.  The
         // kernel writes its status block straight into pinned host memory.
-        ws.pin[0] = 1;
-        RBL_TRY(launch_lasso_fs(G, ld, ld, q, w, reg / (2.0 * rho), ws.pin, s));
-        RBL_HIP(hipEventRecord(ws.fs_done, s));
+        ws.pin[0] = -1;   // sentinel: the kernel stores its status (>= 0) here last
+        RBL_TRY(launch_lasso_fs(G, ld, ld, q, w, reg / (2.0 * rho), ws.pin, s, rho_dev, reg, w_prev_out));
         if (fs_pending) {
             *fs_pending = true;
             return RBL_OK;
@@ -383,7 +382,7 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
 
 int finish_wstep_l1(const double* G, int64_t ld, const double* q, double rho, double reg, double L, double tol,
                     int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s, bool* fell_back) {
-    RBL_HIP(hipEventSynchronize(ws.fs_done));
+    rbl_spin_wait(ws.pin, -1, s);
     const volatile int* st = ws.pin;
     if (st[0] == 0) {
         if (iters_host) *iters_host = st[1];

@@ -124,6 +124,7 @@ class Optimizer:
         self.test_objective = rankbasedObjective(X, y, weight_function, loss, l2_reg, l1_reg, B, n_class, args,
                                                  storage=self._storage, device=self._device)
         w = self.w
+        self._s.profile_kernels(2)     # z_time / w_time below come from HIP events around the phases
         self.w_time = [0]
         self.z_time = [0]
         self.train_losses = [self.objective.get_arrogate_loss(w)]

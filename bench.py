@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--storage", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gap", action="store_true", help="skip the wall-clock-to-1e-6-gap run")
+    ap.add_argument("--phase-times", action="store_true",
+                    help="HIP events around every phase (config.phase_ms_last); costs ~5 us of stream time per event")
     ap.add_argument("--seed", type=int, default=17)
     a = ap.parse_args()
 
@@ -166,7 +168,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    s.profile_kernels(True)
+    s.profile_kernels(2 if a.phase_times else 1)
     s.reset_kernel_times()
     torch.cuda.synchronize()
     if world > 1:
@@ -213,9 +215,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["label"], "rows": n_total, "cols": d, "storage": a.storage,
                        "sharding": f"rows/{world}", "setup_s": round(t_setup, 3),
-                       "inner_iters_last": int(last.inner_iters), "phase_ms_last": {
+                       "inner_iters_last": int(last.inner_iters), "phase_ms_last": ({
                            "z": round(last.ms_z, 3), "q": round(last.ms_q, 3), "w": round(last.ms_w, 3),
-                           "v": round(last.ms_v, 3), "total": round(last.ms_total, 3)},
+                           "v": round(last.ms_v, 3), "total": round(last.ms_total, 3)} if a.phase_times else None),
                        "single_sweep_iterations": n_fused, "rho_mispredictions": n_mispred},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_" + dom,

@@ -89,7 +89,7 @@ typedef struct rbl_stats {
     int32_t inner_iters;     /* w-step inner iterations */
     int32_t ehrm_branch;     /* 0 = a (z<=B), 1 = b (z>=B), -1 = n/a (PAV_cpt.py:222-226) */
     int32_t pav_merges;      /* seam merges performed by the PAV tree, -1 = n/a */
-    float   ms_z, ms_q, ms_w, ms_v, ms_total;  /* device time of the phases, HIP events */
+    float   ms_z, ms_q, ms_w, ms_v, ms_total;  /* device time of the phases, HIP events (rbl_profile_kernels level 2) */
     int32_t fused;           /* 1: this iteration's dual update ran in the single-sweep erm kernel */
     int32_t mispredicted;    /* 1: rho was mispredicted, the next z-step is redone unfused */
 } rbl_stats;
@@ -188,6 +188,9 @@ int  rbl_info(rbl_solver* h, int64_t* ld, int* num_cu, double* lipschitz);
 enum { RBL_KERNEL_GEMV = 0, RBL_KERNEL_GEMVT = 1, RBL_KERNEL_SWEEP_ERM = 2 };
 int  rbl_kernel_time(rbl_solver* h, int which, double* total_ms, int64_t* launches);
 int  rbl_reset_kernel_times(rbl_solver* h);
+/* enable: 0 = no HIP events inside the iteration (default: an event record costs ~5 us of stream
+ * time), 1 = events around the sweep kernels (rbl_kernel_time), 2 = also around the phases (the
+ * ms_* fields of rbl_stats, 0 otherwise) */
 int  rbl_profile_kernels(rbl_solver* h, int enable);
 
 /* ---- kernel-level entry points over host buffers (parity tests call these) -------- */
