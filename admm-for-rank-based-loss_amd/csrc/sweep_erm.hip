@@ -249,6 +249,188 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
     }
 }
 
+// ---- wide rows (more than 4 x 64 packets, e.g. d = 10 000): one WORKGROUP of 8 waves per row
+// batch.  Thread t owns packets t, t+512, ... of every row (PT packets), so w and the column
+// sums stay in registers exactly as in the wave-per-row kernel; the dot product is folded
+// across the 8 waves through LDS (fixed order), the owner lane of each row does the row-wise
+// update + prox, and the coefficients come back through LDS: two workgroup barriers per batch
+// of R rows, hidden behind the next batch's loads already in flight.  Same super-batches of
+// S*R = 16 consecutive rows, same arithmetic per row, one slab row per workgroup.  w lives in
+// LDS ([p][thread][k], up to 128 KB: one workgroup per CU), which leaves the registers to the two
+// row buffers and the column sums.
+constexpr int SEW_THREADS = 512;
+
+template <typename T, int LOSS, int PT, int R, int S>
+__global__ __launch_bounds__(SEW_THREADS, 1) void k_sweep_erm_wide(
+    const T* __restrict__ D, long long n, long long ld, const double* __restrict__ w, const double* __restrict__ z_old,
+    double* __restrict__ lam, double* __restrict__ v, double* __restrict__ z_new, double sigma0, double rho,
+    const double* __restrict__ pred, double* __restrict__ slab, double* __restrict__ partials) {
+    constexpr int E = Pk<T>::E;
+    constexpr int NW = SEW_THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int PK = (int)(ld / E);
+    const unsigned row_bytes = (unsigned)ld * (unsigned)sizeof(T);
+    const double rho_next = pred[0];
+
+    extern __shared__ __align__(16) double sw_wide[];   // PT * 512 * E doubles
+    double acc[PT][E];
+    int boff[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        int pkp = tid + SEW_THREADS * p;
+        const bool ok = pkp < PK;
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            sw_wide[(p * SEW_THREADS + tid) * E + k] = ok ? w[(long long)pkp * E + k] : 0.0;
+            acc[p][k] = 0.0;
+        }
+        if (!ok) pkp = PK - 1;  // tail threads re-read the last packet; w == 0 and the sums are dropped
+        boff[p] = pkp * 16;
+    }
+    double s_prim = 0.0, s_zz = 0.0;   // (each thread reads back only what it wrote: no barrier needed for sw_wide)
+
+    constexpr int SR = S * R;
+    const int nsuper = (int)((n + SR - 1) / SR);
+    const int live_last = (int)(n - (long long)(nsuper - 1) * SR);
+    const int GW = (int)gridDim.x;
+
+    __shared__ double part[NW][R];   // per-wave partial dot products of the batch
+    __shared__ double cshare[R];     // coefficients of the batch's rows
+
+    auto load_side = [&](int q, double& zo, double& lm) {
+        const int live = q == nsuper - 1 ? live_last : SR;
+        const bool mine = tid < live;
+        const long long myrow = (long long)q * SR + tid;
+        zo = mine ? z_old[myrow] : 0.0;
+        lm = mine ? lam[myrow] : 0.0;
+    };
+    auto load_rows = [&](int q, int sub, u32x4 (&buf)[R][PT]) {
+        const int live = q == nsuper - 1 ? live_last : SR;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int i = sub * R + r;
+            if (i >= live) i = live - 1;
+            const long long row = (long long)q * SR + i;
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(D + row * ld), 0, (int)row_bytes, 0x00020000);
+#pragma unroll
+            for (int p = 0; p < PT; ++p) buf[r][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[p], 0, 0);
+        }
+    };
+
+    double l_out = 0.0, v_out = 0.0, z_out = 0.0;
+    auto process = [&](int live, int sub, u32x4 (&buf)[R][PT], double zo, double lm) {
+        double dot[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) dot[r] = 0.0;
+        int woff = tid * E;   // opaque: keeps the loop-invariant LDS reads of w from being hoisted into registers
+        asm volatile("" : "+v"(woff));
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            double wv[E];
+#pragma unroll
+            for (int k = 0; k < E; ++k) wv[k] = sw_wide[p * SEW_THREADS * E + woff + k];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int k = 0; k < E; ++k) dot[r] = __builtin_fma(Pk<T>::at(buf[r][p], k), wv[k], dot[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            dot[r] = rbl::wave_sum_all(dot[r]);
+            if (lane == 0) part[wave][r] = dot[r];
+        }
+        __syncthreads();
+        double c = 0.0;
+        if (tid >= sub * R && tid < sub * R + R && tid < live) {   // owner of row q*SR + tid (wave 0)
+            const int r = tid - sub * R;
+            double myv = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) myv += part[wv][r];
+            const double res = zo - myv;
+            const double l = lm + rho * res;                       // algorithms.py:132
+            s_prim += res * res;                                   // algorithms.py:135
+            const double lr = l / rho_next;
+            const double m = myv - lr;                             // algorithms.py:89 (next iteration)
+            const double zn = (LOSS == 0) ? rbl::prox_bce_warm(sigma0, rho_next, m, zo) : rbl::prox_hinge(sigma0, rho_next, m);
+            s_zz += zn * zn;
+            l_out = l;
+            v_out = myv;
+            z_out = zn;
+            c = zn + lr;
+        }
+        if (tid >= sub * R && tid < sub * R + R) cshare[tid - sub * R] = c;   // 0 for rows past n
+        opaque<T>(buf);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double cr = cshare[r];
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+#pragma unroll
+                for (int k = 0; k < E; ++k) acc[p][k] = __builtin_fma(Pk<T>::at(buf[r][p], k), cr, acc[p][k]);
+        }
+    };
+
+    // One copy of the row-wise code: the prefetch always lands in bufB and is moved to bufA once
+    // bufA has been consumed (R*PT register moves per batch; unrolling the loop by two instead
+    // would duplicate the inlined prox and its constants and spill).
+    u32x4 bufA[R][PT], bufB[R][PT];
+    double zo = 0.0, lm = 0.0, zoN = 0.0, lmN = 0.0;
+    int q = (int)blockIdx.x, sub = 0;
+    if (q < nsuper) {
+        load_side(q, zo, lm);
+        load_rows(q, 0, bufA);
+    }
+#pragma clang loop unroll(disable)
+    while (q < nsuper) {
+        const int live = q == nsuper - 1 ? live_last : SR;
+        const bool last = sub + 1 == S;
+        const int qn = last ? q + GW : q;
+        const int subn = last ? 0 : sub + 1;
+        if (qn < nsuper) {
+            if (last) load_side(qn, zoN, lmN);
+            load_rows(qn, subn, bufB);
+        }
+        process(live, sub, bufA, zo, lm);
+        if (last) {
+            if (tid < live) {
+                const long long row = (long long)q * SR + tid;
+                lam[row] = l_out;
+                v[row] = v_out;
+                z_new[row] = z_out;
+            }
+            zo = zoN;
+            lm = lmN;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) bufA[r][p] = bufB[r][p];
+        q = qn;
+        sub = subn;
+    }
+
+    // every thread owns its columns: the slab row of this workgroup is written directly
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int pkp = tid + SEW_THREADS * p;
+        if (pkp < PK) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) slab[(long long)blockIdx.x * ld + (long long)pkp * E + k] = acc[p][k];
+        }
+    }
+    __syncthreads();
+    double sums[3] = {s_prim, 0.0, s_zz};
+    __shared__ double smem[3 * NW];
+    rbl::block_sum<3, SEW_THREADS>(sums, smem);
+    if (tid == 0) {
+        partials[blockIdx.x * 3 + 0] = sums[0];
+        partials[blockIdx.x * 3 + 1] = sums[1];
+        partials[blockIdx.x * 3 + 2] = sums[2];
+    }
+}
+
 // Column sums of the nb slab rows in two steps: CR_SLICES x ceil(ld/64) blocks each fold their share
 // of the rows into part[slice][ld] (fixed order), k_finish_sweep adds the slices.
 constexpr int CR_SLICES = 8;
@@ -361,9 +543,36 @@ int launch_T(const T* D, long long n, long long ld, const double* w, const doubl
     if (passes == 1) return launch_one<T, LOSS, 1, 8, 2, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
     if (passes == 2) return launch_one<T, LOSS, 2, 4, 4, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
     if (passes <= 4) return launch_one<T, LOSS, 4, 2, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
-    // 5..8 passes only exist for fp64 storage (sweep_erm_supported caps both types at d <= 1024)
-    if constexpr (sizeof(T) == 8)
-        return launch_one<T, LOSS, 8, 1, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+    if (passes <= 8 && sizeof(T) == 8) {
+        if constexpr (sizeof(T) == 8)
+            return launch_one<T, LOSS, 8, 1, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+    }
+    // wider rows: one workgroup of 512 threads per row batch (grid = one workgroup per CU)
+    const long long pt = (PK + SEW_THREADS - 1) / SEW_THREADS;
+    const int wgrid = grid / 2;
+#define RBL_WIDE(PT_, R_, S_)                                                                                          \
+    do {                                                                                                               \
+        auto kfn = k_sweep_erm_wide<T, LOSS, PT_, R_, S_>;                                                             \
+        const size_t lds = (size_t)PT_ * SEW_THREADS * Pk<T>::E * sizeof(double);                                      \
+        static bool attr_set = false;                                                                                  \
+        if (!attr_set) {                                                                                               \
+            RBL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lds));                                                                    \
+            attr_set = true;                                                                                           \
+        }                                                                                                              \
+        hipLaunchKernelGGL(kfn, dim3(wgrid), dim3(SEW_THREADS), lds, s, D, n, ld, w, z_old, lam, v, z_new, sigma0, rho,  \
+                           pred, slab, partials);                                                                      \
+        RBL_HIP(hipGetLastError());                                                                                    \
+        return RBL_OK;                                                                                                 \
+    } while (0)
+    if (pt <= 2) RBL_WIDE(2, 4, 4);
+    if (pt <= 3) RBL_WIDE(3, 4, 4);
+    if (pt <= 4) RBL_WIDE(4, 2, 8);
+    if (pt <= 5) RBL_WIDE(5, 2, 8);
+    if (pt <= 6) RBL_WIDE(6, 2, 8);
+    if (pt <= 8) RBL_WIDE(8, 1, 16);
+#undef RBL_WIDE
+    rbl_set_error("single-sweep kernel: d=%lld too wide", (long long)ld);
     return RBL_ERR_INVALID;
 }
 
@@ -371,8 +580,14 @@ int launch_T(const T* D, long long n, long long ld, const double* w, const doubl
 
 bool sweep_erm_supported(int storage, int64_t ld) {
     const int64_t PK = ld / (storage == RBL_STORE_F32 ? 4 : 2);
-    // d <= 1024 in both storage types (the wider fp32 variant would spill registers)
-    return PK > 32 && PK <= (storage == RBL_STORE_F32 ? 256 : 512);
+    // wave-per-row kernel up to 4 (fp32) / 8 (fp64) passes of 64 packets, workgroup-per-row
+    // kernel up to 8 packets per thread: d <= 16384 (fp32) / 8192 (fp64)
+    return PK > 32 && PK <= 8 * SEW_THREADS;
+}
+// the wide kernel runs one workgroup per CU and reports its slab rows / partials as such
+static bool sweep_erm_is_wide(int storage, int64_t ld) {
+    const int64_t PK = ld / (storage == RBL_STORE_F32 ? 4 : 2);
+    return PK > (storage == RBL_STORE_F32 ? 256 : 512);
 }
 
 int sweep_erm_blocks(int num_cu) { return num_cu * 2; }  // 2 blocks of 4 waves per CU (2 waves per SIMD)
@@ -383,6 +598,7 @@ int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld
                      double* slab, double* partials, double* q, double* red, double* zz_out, int num_cu, hipStream_t s,
                      hipEvent_t main_done, int want_obj) {
     const int grid = sweep_erm_blocks(num_cu);
+    const int nrows = sweep_erm_is_wide(storage, ld) ? grid / 2 : grid;   // slab rows / partial triples produced
     int rc;
     if (storage == RBL_STORE_F32) {
         rc = (loss == RBL_LOSS_BCE)
@@ -396,9 +612,9 @@ int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld
     RBL_TRY(rc);
     if (main_done) RBL_HIP(hipEventRecord(main_done, s));
     double* part = slab + (size_t)grid * ld;   // CR_SLICES rows behind the grid rows of the slab
-    hipLaunchKernelGGL(k_colreduce2, dim3((unsigned)((ld + 63) / 64), CR_SLICES), dim3(256), 0, s, slab, grid, (long long)ld,
+    hipLaunchKernelGGL(k_colreduce2, dim3((unsigned)((ld + 63) / 64), CR_SLICES), dim3(256), 0, s, slab, nrows, (long long)ld,
                        part);
-    hipLaunchKernelGGL(k_finish_sweep, dim3(1), dim3(256), 0, s, part, (long long)ld, q, partials, grid, red, zz_out);
+    hipLaunchKernelGGL(k_finish_sweep, dim3(1), dim3(256), 0, s, part, (long long)ld, q, partials, nrows, red, zz_out);
     RBL_HIP(hipGetLastError());
     // objective.py:11-24: the per-sample losses are summed from v in a pass of their own (8 B per
     // row) - exp/log1p inside the sweep cost registers on its critical path

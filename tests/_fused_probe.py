@@ -12,9 +12,12 @@ import admm_for_rank_based_loss_amd as rbl  # noqa: E402
 from oracle import problems  # noqa: E402
 
 loss, reg_kind = sys.argv[1], sys.argv[2]
-X, y = problems.make_problem(3000, 160, seed=21)
+rows = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
+cols = int(sys.argv[4]) if len(sys.argv) > 4 else 160
+storage = sys.argv[5] if len(sys.argv) > 5 else "f64"
+X, y = problems.make_problem(rows, cols, seed=21)
 kw = {reg_kind: 0.01}
-s = rbl.ADMMmethod(X, y, "erm", loss, storage="f64", tol=0.0, max_iter=40, **kw)
+s = rbl.ADMMmethod(X, y, "erm", loss, storage=storage, tol=0.0, max_iter=40, **kw)
 hist, fused, mis = [], 0, 0
 for i in range(40):
     st = s._s.step(True)

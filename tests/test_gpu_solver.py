@@ -355,6 +355,39 @@ def test_single_sweep_paths(loss, reg_kind):
             1.0, np.max(np.abs(runs["fused"]["lam"])))
 
 
+@pytest.mark.parametrize("rows,cols,storage,loss,reg_kind", [
+    (700, 1100, "f32", "binary_cross_entropy", "l1_reg"),    # workgroup-per-row kernel, 2 packets per thread
+    (517, 2300, "f32", "hinge", "l2_reg"),                   # 5 packets per thread, ragged last super-batch
+    (300, 3100, "f64", "binary_cross_entropy", "l1_reg"),    # fp64 storage, 4 packets per thread
+    (260, 7000, "f32", "binary_cross_entropy", "l2_reg"),    # 4 packets per thread, d >> n
+    (1030, 900, "f64", "hinge", "l1_reg"),                   # wave-per-row kernel, 8 passes (fp64 only)
+])
+def test_single_sweep_wide_rows(rows, cols, storage, loss, reg_kind):
+    """The single-sweep path for every row width (sweep_erm.hip: wave-per-row up to 4 / 8 passes,
+    workgroup-per-row above): same iterates as the two-sweep path on the same data and storage."""
+    import subprocess
+    import sys
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    runs = {}
+    for name, env in (("fused", {}), ("unfused", {"RBL_NO_FUSE": "1"})):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, os.path.join(here, "_fused_probe.py"), loss, reg_kind, str(rows), str(cols),
+                              storage], env=e, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        runs[name] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert runs["fused"]["fused"] >= 38 and runs["fused"]["mispredicted"] == 0
+    assert runs["unfused"]["fused"] == 0
+    hf, hu = np.array(runs["fused"]["hist"]), np.array(runs["unfused"]["hist"])
+    assert np.array_equal(hf[:, 2], hu[:, 2])                       # same rho schedule
+    assert np.allclose(hf[:, 0], hu[:, 0], rtol=1e-9, atol=1e-12)   # primal residual
+    assert np.allclose(hf[:, 3], hu[:, 3], rtol=1e-10)              # objective
+    for key in ("w", "z", "lam"):
+        a, b = np.array(runs["fused"][key]), np.array(runs["unfused"][key])
+        assert np.max(np.abs(a - b)) <= 1e-10 * max(1.0, np.max(np.abs(b))), key
+
+
 @pytest.mark.parametrize("n,d", [(2, 1), (3, 2), (17, 3), (64, 5), (100, 1), (257, 33), (40, 90), (1000, 7)])
 def test_small_and_odd_shapes(R, n, d):
     """Edge shapes through the whole iteration (single rows, d = 1, d > n, sizes that are not
