@@ -38,46 +38,70 @@ __global__ __launch_bounds__(256) void k_gram(const T* __restrict__ D, long long
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    bool cia[4], cjb[4];
-    long long coli[4], colj[4];
+    // Operands come straight from global memory (a lane needs D[r + lane/16][c0 + 16 s + lane%16]:
+    // 64-byte row segments, L1/L2 absorb the reuse between the 4 waves), as buffer loads:
+    // scalar descriptor = the step's first row, per-lane offset = (lane/16) rows + column, and
+    // num_records = the bytes left in this split, so rows past its end - and columns past ld,
+    // whose offset is pushed out of range - read as 0 with no per-load address arithmetic.
+    // DEPTH steps are kept in flight (raw storage type in registers, widened at use): one step
+    // is 16 MFMAs = ~1000 cycles of matrix pipe per wave, loaded HBM latency is several times that.
+    constexpr int DEPTH = 4;
+    constexpr unsigned OOB = 0x7fffffffu;
+    unsigned offa[4], offb[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        coli[s] = ci0 + 16 * s + lc;
-        colj[s] = cj0 + 16 * s + lc;
-        cia[s] = coli[s] < ld;
-        cjb[s] = colj[s] < ld;
-        if (!cia[s]) coli[s] = 0;
-        if (!cjb[s]) colj[s] = 0;
+        const long long ca = ci0 + 16 * s + lc, cb = cj0 + 16 * s + lc;
+        offa[s] = ca < ld ? (unsigned)(((long long)lk * ld + ca) * (long long)sizeof(T)) : OOB;
+        offb[s] = cb < ld ? (unsigned)(((long long)lk * ld + cb) * (long long)sizeof(T)) : OOB;
     }
+    const long long row_bytes = ld * (long long)sizeof(T);
 
-    auto load_step = [&](long long r, double (&a)[4], double (&b)[4]) {
-        long long row = r + lk;
-        const bool rv = row < r_end;
-        if (!rv) row = r_begin;
-        const T* rp = D + row * ld;
+    T ra[DEPTH][4], rb[DEPTH][4];
+    auto load_step = [&](long long r, T (&a)[4], T (&b)[4]) {
+        long long left = (r_end - r) * row_bytes;   // bytes of this split from row r on (<= 0: nothing)
+        if (left < 0) left = 0;
+        if (left > 4 * row_bytes) left = 4 * row_bytes;
+        const long long rr = r < r_end ? r : r_begin;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(D + rr * ld), 0, (int)left, 0x00020000);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            a[s] = (rv && cia[s]) ? (double)rp[coli[s]] : 0.0;
-            b[s] = (rv && cjb[s]) ? (double)rp[colj[s]] : 0.0;
+            if constexpr (sizeof(T) == 4) {
+                a[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)offa[s], 0, 0));
+                b[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)offb[s], 0, 0));
+            } else {
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 va = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)offa[s], 0, 0);
+                const u32x2 vb = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)offb[s], 0, 0);
+                a[s] = __hiloint2double((int)va[1], (int)va[0]);
+                b[s] = __hiloint2double((int)vb[1], (int)vb[0]);
+            }
         }
+    };
+    auto mfma_step = [&](const T (&a)[4], const T (&b)[4]) {
+        double da[4], db[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            da[s] = (double)a[s];
+            db[s] = (double)b[s];
+        }
+#pragma unroll
+        for (int si = 0; si < 4; ++si)
+#pragma unroll
+            for (int sj = 0; sj < 4; ++sj)
+                acc[si][sj] = __builtin_amdgcn_mfma_f64_16x16x4f64(da[si], db[sj], acc[si][sj], 0, 0, 0);
     };
 
     if (r_begin < r_end) {
-        double a0[4], b0[4], a1[4], b1[4];
-        load_step(r_begin, a0, b0);
-        for (long long r = r_begin; r < r_end; r += 8) {
-            load_step(r + 4, a1, b1);  // rows beyond r_end load zeros
 #pragma unroll
-            for (int si = 0; si < 4; ++si)
+        for (int k = 0; k < DEPTH - 1; ++k) load_step(r_begin + 4 * k, ra[k], rb[k]);
+        for (long long r = r_begin; r < r_end; r += 4 * DEPTH) {
 #pragma unroll
-                for (int sj = 0; sj < 4; ++sj)
-                    acc[si][sj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[si], b0[sj], acc[si][sj], 0, 0, 0);
-            load_step(r + 8, a0, b0);
-#pragma unroll
-            for (int si = 0; si < 4; ++si)
-#pragma unroll
-                for (int sj = 0; sj < 4; ++sj)
-                    acc[si][sj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[si], b1[sj], acc[si][sj], 0, 0, 0);
+            for (int k = 0; k < DEPTH; ++k) {
+                // the step DEPTH-1 ahead goes into the slot consumed in the previous sub-step
+                load_step(r + 4 * (k + DEPTH - 1), ra[(k + DEPTH - 1) % DEPTH], rb[(k + DEPTH - 1) % DEPTH]);
+                mfma_step(ra[k], rb[k]);   // rows past r_end were loaded as zeros
+            }
         }
     }
 
