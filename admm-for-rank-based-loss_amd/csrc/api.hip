@@ -74,6 +74,7 @@ struct rbl_solver {
     // single-sweep erm iteration (sweep_erm.hip)
     bool fused_ok = false, z_ready = false, p_valid = false, p_pending = false, pred_valid = false, fused_ran = false;
     bool red_owned = false;
+    bool fuse_v = false;   // rank-weighted problems: v = D w fused with the lambda update (sweep_erm.hip, SE_VONLY)
     int pending_mask = 0;  // bit 0: the q part, bit 1: the residual part of the exchange buffer awaits a sum over ranks
     double *z_next = nullptr, *p = nullptr, *p_alt = nullptr, *pred = nullptr;
     double* hstat = nullptr;   // pinned host block the end-of-iteration statistics are packed into by the device
@@ -509,6 +510,7 @@ int rbl_create(const rbl_config* cfg, rbl_solver** out) {
             {
                 const char* nf = getenv("RBL_NO_FUSE");
                 h->fused_ok = !h->sorted_path && !(nf && nf[0] == '1') && sweep_erm_supported(h->storage, ld);
+                h->fuse_v = !h->fused_ok && !(nf && nf[0] == '1') && n > 0 && sweep_v_supported(h->storage, ld);
                 if (h->fused_ok) {
                     CK(dev_alloc(&h->z_next, (size_t)n));
                     CK(dev_alloc(&h->p, (size_t)ld));
@@ -942,6 +944,14 @@ int rbl_phase_dual(rbl_solver* h, int want_objective) {
                                  h->num_cu, h->stream, h->profile ? h->kev[5] : nullptr, want_objective));
         if (h->profile) h->kev_pending[2] = h->n > 0;
         h->fused_ran = true;
+        h->v_valid = true;
+        if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[4], h->stream));
+    } else if (h->fuse_v) {
+        // v = D w and the lambda update in one pass (timed as the gemv of the iteration)
+        if (h->profile) RBL_HIP(hipEventRecord(h->kev[0], h->stream));
+        RBL_TRY(launch_sweep_v(h->storage, h->D, h->n, h->ld, h->w, h->z, h->lam, h->v, h->step_rho, h->partials, h->red,
+                               h->num_cu, h->stream, h->profile ? h->kev[1] : nullptr));
+        if (h->profile) h->kev_pending[0] = h->n > 0;
         h->v_valid = true;
         if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[4], h->stream));
     } else {

@@ -187,6 +187,10 @@ int launch_predict_rho(int64_t ld, const double* q, const double* p, double* p_o
                        const double* Gw, const double* zz, double rho, double cap, double* pred, double* wstats,
                        hipStream_t s, const double* rho_dev = nullptr);
 int launch_sumsq(int64_t n, const double* x, double* partials, double* out, hipStream_t s);
+// v = D w, lambda += rho (z - v), red[0] = sum (z - v)^2 in one pass (rows up to 4 / 8 passes of 64 packets)
+bool sweep_v_supported(int storage, int64_t ld);
+int launch_sweep_v(int storage, const void* D, int64_t n, int64_t ld, const double* w, const double* z, double* lam,
+                   double* v, double rho, double* partials, double* red, int num_cu, hipStream_t s, hipEvent_t main_done);
 int launch_symv(const double* G, int64_t ld, const double* x, double* y, hipStream_t s);
 
 // ---- gram.hip ---------------------------------------------------------------------------

@@ -52,8 +52,11 @@ __device__ inline void opaque(u32x4 (&buf)[R][P]) {
 }
 
 // pred[0] = rho_{k+1} (predicted), read on the device so no host round trip is needed
-// EXP != 0 only in tools/sweep_lab.hip (ablation timings: which phase costs what); the library
-// instantiates EXP == 0 alone.
+// EXP selects what is left out.  The library instantiates EXP == 0 (everything) and
+// EXP == SE_VONLY (rank-weighted problems: v = D w, the lambda update and the primal residual
+// only - the z-step needs the global sort and q a second pass); the other values exist for
+// tools/sweep_lab.hip (ablation timings: which phase costs what).
+constexpr int SE_VONLY = 2 | 4 | 128;   // no accumulation phase, no prox, no z' / slab output
 template <typename T, int LOSS, int P, int R, int S, bool WL, int EXP = 0>
 __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
     const T* __restrict__ D, long long n, long long ld, const double* __restrict__ w, const double* __restrict__ z_old,
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int PK = (int)(ld / E);
     const unsigned row_bytes = (unsigned)ld * (unsigned)sizeof(T);
-    const double rho_next = pred[0];
+    const double rho_next = (EXP & 128) ? 1.0 : pred[0];
 
     // w: in registers, or (WL) in LDS, one copy per block, laid out [p][lane][k] so that a
     // lane's E values are contiguous - frees 2*P*E VGPRs for a second pair of row buffers
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
                 const long long row = (long long)q * SR + lane;
                 lam[row] = l_out;
                 v[row] = v_out;
-                z_new[row] = z_out;
+                if (!(EXP & 128)) z_new[row] = z_out;
             }
             zo = zoN;
             lm = lmN;
@@ -223,22 +226,24 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
     }
 
     // fold the 4 waves' column sums in LDS, one slab row per block
-    __shared__ double red[SE_THREADS / 64][64 * P * E];
+    __shared__ double red[(EXP & 128) ? 1 : SE_THREADS / 64][(EXP & 128) ? 1 : 64 * P * E];
+    if (!(EXP & 128)) {
 #pragma unroll
-    for (int p = 0; p < P; ++p)
+        for (int p = 0; p < P; ++p)
 #pragma unroll
-        for (int k = 0; k < E; ++k) red[wave][(p * 64 + lane) * E + k] = acc[p][k];
-    __syncthreads();
-    for (int i = tid; i < 64 * P * E; i += SE_THREADS) {
-        const long long col = i;  // packet (p*64+lane), element k  ->  column (p*64+lane)*E + k
-        if (col < ld) {
-            double s = 0.0;
+            for (int k = 0; k < E; ++k) red[wave][(p * 64 + lane) * E + k] = acc[p][k];
+        __syncthreads();
+        for (int i = tid; i < 64 * P * E; i += SE_THREADS) {
+            const long long col = i;  // packet (p*64+lane), element k  ->  column (p*64+lane)*E + k
+            if (col < ld) {
+                double s = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < SE_THREADS / 64; ++wv) s += red[wv][i];
-            slab[(long long)blockIdx.x * ld + col] = s;
+                for (int wv = 0; wv < SE_THREADS / 64; ++wv) s += red[wv][i];
+                slab[(long long)blockIdx.x * ld + col] = s;
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     double sums[3] = {s_prim, 0.0, s_zz};   // slot 1: the loss sum, filled by k_loss_sum when wanted
     __shared__ double smem[3 * SE_THREADS / 64];
     rbl::block_sum<3, SE_THREADS>(sums, smem);
@@ -619,6 +624,63 @@ int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld
     // objective.py:11-24: the per-sample losses are summed from v in a pass of their own (8 B per
     // row) - exp/log1p inside the sweep cost registers on its critical path
     if (want_obj) RBL_TRY(launch_loss_sum(loss, n, v, 1.0, partials, red + 1, s));
+    return RBL_OK;
+}
+
+namespace {
+// red[0] = sum primal^2, red[1] = 0 (k_loss_sum fills it when wanted)
+__global__ __launch_bounds__(256) void k_finish_v(const double* __restrict__ partials, int nb, double* __restrict__ red) {
+    __shared__ double smem[4];
+    double a[1] = {0.0};
+    for (int b = threadIdx.x; b < nb; b += 256) a[0] += partials[b * 3];
+    rbl::block_sum<1, 256>(a, smem);
+    if (threadIdx.x == 0) {
+        red[0] = a[0];
+        red[1] = 0.0;
+    }
+}
+
+template <typename T>
+int launch_v_T(const T* D, long long n, long long ld, const double* w, const double* z, double* lam, double* v, double rho,
+               double* partials, int grid, hipStream_t s) {
+    const long long PK = ld / Pk<T>::E;
+    const long long passes = (PK + 63) / 64;
+#define RBL_V(P_, R_, S_)                                                                                           \
+    do {                                                                                                            \
+        hipLaunchKernelGGL((k_sweep_erm<T, 1, P_, R_, S_, false, SE_VONLY>), dim3(grid), dim3(SE_THREADS), 0, s, D, n, \
+                           ld, w, z, lam, v, (double*)nullptr, 0.0, rho, (const double*)nullptr, (double*)nullptr,  \
+                           partials);                                                                               \
+        RBL_HIP(hipGetLastError());                                                                                 \
+        return RBL_OK;                                                                                              \
+    } while (0)
+    if (passes == 1) RBL_V(1, 8, 2);
+    if (passes == 2) RBL_V(2, 4, 4);
+    if (passes <= 4) RBL_V(4, 2, 8);
+    if constexpr (sizeof(T) == 8) {
+        if (passes <= 8) RBL_V(8, 1, 8);
+    }
+#undef RBL_V
+    return RBL_ERR_INVALID;
+}
+}  // namespace
+
+// rank-weighted problems: v = D w, lambda += rho (z - v), red[0] = sum (z - v)^2 in one pass
+// (replaces k_gemv + k_dual when the row width fits the wave-per-row kernel)
+bool sweep_v_supported(int storage, int64_t ld) {
+    const int64_t PK = ld / (storage == RBL_STORE_F32 ? 4 : 2);
+    return PK > 32 && PK <= (storage == RBL_STORE_F32 ? 256 : 512);
+}
+
+int launch_sweep_v(int storage, const void* D, int64_t n, int64_t ld, const double* w, const double* z, double* lam,
+                   double* v, double rho, double* partials, double* red, int num_cu, hipStream_t s, hipEvent_t main_done) {
+    const int grid = sweep_erm_blocks(num_cu);
+    if (storage == RBL_STORE_F32)
+        RBL_TRY(launch_v_T<float>((const float*)D, n, ld, w, z, lam, v, rho, partials, grid, s));
+    else
+        RBL_TRY(launch_v_T<double>((const double*)D, n, ld, w, z, lam, v, rho, partials, grid, s));
+    if (main_done) RBL_HIP(hipEventRecord(main_done, s));
+    hipLaunchKernelGGL(k_finish_v, dim3(1), dim3(256), 0, s, partials, grid, red);
+    RBL_HIP(hipGetLastError());
     return RBL_OK;
 }
 
