@@ -5,9 +5,12 @@ The reference is single-process; the sample axis shards like this
 (SURVEY 8e):  rank r holds rows [r*nmax, min((r+1)*nmax, n)) of D and the matching slices
 of v, m, z, lambda; w, G, sigma are replicated.  Per iteration:
   1. local  m = D w - lambda/rho                                  (engine.phase_m)
-  2. rank weights only: all-gather m (8n bytes) so that every rank can rank its rows
-     globally, then the z-step on the gathered vector, keeping the local slice
-                                                                   (engine.phase_z)
+  2. rank weights only: the z-step needs the GLOBAL order of m.  Distributed form (default
+     when the engine has the zd_* methods): splitter-based sample sort so that rank r owns a
+     contiguous range of the sorted order, exact PAV on the own chunk, then a merge tree over
+     ranks whose seams are resolved by a K-ary search that exchanges only (count, sum sigma,
+     sum m) summaries; z goes back to the rows' owners (``_z_distributed``).  Replicated form
+     (``dist_z=False``): all-gather m (8n bytes), z-step on the gathered vector on every rank.
      erm needs no exchange: z_i = prox(m_i) is local.
   3. local  q = D^T (z + lambda/rho), all-reduce(sum) of q (d doubles)   (phase_q)
   4. replicated d-space w-step                                     (engine.phase_w)
@@ -108,13 +111,18 @@ class GpuEngine:
 class ShardedADMM:
     """Drives one engine per rank through the phases with the collectives in between."""
 
-    def __init__(self, engine, group=None):
+    NS = 64      # regular samples per rank for the splitters
+    K = 15       # seam-search candidates per rank and round
+
+    def __init__(self, engine, group=None, dist_z=True):
         self.e = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         _, _, self.nmax = shard_rows(engine.n_total, self.world, self.rank)
         self._gather = None
+        self.dist_z = bool(dist_z) and hasattr(engine, "zd_sort_local")
+        self._stage = dist.is_initialized() and dist.get_backend(group) == "gloo"
 
     def _allreduce(self, t):
         if self.world > 1 and t.numel() > 0:
@@ -134,6 +142,86 @@ class ShardedADMM:
         dist.all_gather_into_tensor(self._gather, pad, group=self.group)
         return self._gather[: self.e.n_total]
 
+    # ------------------------------------------------------- distributed z-step (rank weights)
+    def _gather_small(self, t):
+        out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        return out
+
+    def _gather_counts(self, counts):
+        """every rank's count list -> (world, world) matrix on the host: row r = what r sends"""
+        t = torch.tensor(counts, dtype=torch.int64)
+        if not self._stage:
+            t = t.to(self.e.device)
+        return self._gather_small(t).cpu().numpy().reshape(self.world, self.world)
+
+    def _alltoall(self, send, send_counts, recv, recv_counts):
+        sc, rc = [int(c) for c in send_counts], [int(c) for c in recv_counts]
+        if self._stage and send.is_cuda:       # gloo moves host memory: stage (tests on one GPU only)
+            r = torch.empty(recv.numel(), dtype=recv.dtype)
+            dist.all_to_all_single(r, send.cpu(), rc, sc, group=self.group)
+            recv.copy_(r)
+        else:
+            dist.all_to_all_single(recv, send, rc, sc, group=self.group)
+
+    @staticmethod
+    def _splitters(samples_all, world):
+        s = samples_all[~torch.isnan(samples_all)]
+        if s.numel() == 0:
+            return torch.full((world - 1,), float("inf"), dtype=torch.float64, device=samples_all.device)
+        s, _ = torch.sort(s)
+        idx = [min(s.numel() - 1, (j + 1) * s.numel() // world) for j in range(world - 1)]
+        return s[idx].contiguous()
+
+    def _z_distributed(self):
+        """z-step for rank weights with the sorted order partitioned over the ranks (the CPU
+        restatement of every engine call is oracle/zdist.py)."""
+        from math import ceil, log2
+        e, P, K = self.e, self.world, self.K
+        # 1. sample sort: splitters from regular samples, rows to the owners of their key range
+        samples_all = self._gather_small(e.zd_sort_local(self.NS))
+        send_counts = e.zd_partition(self._splitters(samples_all, P))
+        cm = self._gather_counts(send_counts)
+        recv_counts = cm[:, self.rank]
+        totals = cm.sum(axis=0)
+        nrecv, off = int(totals[self.rank]), int(totals[: self.rank].sum())
+        sk, si = e.zd_send_buffers()
+        rk, ri = e.zd_recv_buffers(nrecv)
+        self._alltoall(sk, send_counts, rk, recv_counts)
+        self._alltoall(si, send_counts, ri, recv_counts)
+        # 2. exact PAV of the own chunk (EHRM: the branch test sums two scalars over the ranks)
+        fv = e.zd_prepare(nrecv, off)
+        self._allreduce(fv)
+        e.zd_pav(fv)
+        # 3. merge tree over ranks
+        nseams = (P + 1) // 2
+        rounds = 1
+        s = int(totals.max())
+        while s > K:
+            s //= (K + 1)
+            rounds += 1
+        rounds += 1
+        for level in range(1, int(ceil(log2(P))) + 1):
+            bounds_all = self._gather_small(e.zd_bounds())
+            e.zd_seam_setup(self.rank, P, level, bounds_all)
+            cand_all = part = None
+            for _ in range(rounds):
+                cand_all = self._gather_small(e.zd_seam_propose(K, cand_all, part))
+                part = e.zd_seam_eval(K, cand_all)
+                self._allreduce(part)
+            sums = e.zd_seam_sums(K, cand_all, part, nseams)
+            self._allreduce(sums)
+            e.zd_seam_fill(sums, nseams)
+        # 4. block values back to the owners of the rows
+        back_counts = e.zd_return_partition(self.nmax, P)
+        bm = self._gather_counts(back_counts)
+        n_back = int(bm[:, self.rank].sum())
+        bi, bu = e.zd_back_send()
+        zi, zu = e.zd_back_recv(n_back)
+        self._alltoall(bi, back_counts, zi, bm[:, self.rank])
+        self._alltoall(bu, back_counts, zu, bm[:, self.rank])
+        e.zd_scatter(n_back)
+
     # ------------------------------------------------------------------- one-time setup
     def setup_synthetic(self, seed=17, class_sep=1.0, flip_y=0.01):
         self.e.synth_local(seed, class_sep, flip_y)
@@ -149,10 +237,13 @@ class ShardedADMM:
     def step(self, want_objective=False):
         e = self.e
         e.phase_m()
-        m_all = None
-        if e.sorted_path and self.world > 1:
-            m_all = self._allgather_rows(e.buf("m"))
-        e.phase_z(m_all)
+        if e.sorted_path and self.world > 1 and self.dist_z:
+            self._z_distributed()
+        else:
+            m_all = None
+            if e.sorted_path and self.world > 1:
+                m_all = self._allgather_rows(e.buf("m"))
+            e.phase_z(m_all)
         e.phase_q()
         pending = getattr(e, "pending_reduce", None)
         if pending is None:                       # plain engines: q and the residuals are two buffers

@@ -7,7 +7,7 @@ import types
 import numpy as np
 import torch
 
-from oracle import admm, prox, weights, wstep, objective
+from oracle import admm, prox, weights, wstep, objective, zdist
 
 
 class NumpyEngine:
@@ -94,3 +94,103 @@ class NumpyEngine:
     def risk_from_v(self, v_all):
         v = np.sort(objective.sample_losses(self.loss, v_all.numpy()))
         return float(np.dot(self.sa, v))
+
+
+    # ---------------------------------------------------------------- distributed z-step
+    # (same protocol as GpuEngine; the arithmetic is oracle/zdist.py)
+    def zd_sort_local(self, nsamples):
+        m = self.bufs["m"].numpy()
+        order = np.argsort(m, kind="stable")
+        self._zd_m = m[order].copy()
+        self._zd_ids = (order + self.off).astype(np.int32)
+        out = np.full(nsamples, np.nan)
+        n = self.n_local
+        for j in range(min(nsamples, n)):
+            out[j] = self._zd_m[min(n - 1, ((j + 1) * n) // (nsamples + 1))] if n > nsamples else self._zd_m[j]
+        return torch.from_numpy(out)
+
+    def zd_partition(self, splitters):
+        sp = splitters.numpy()
+        dest = np.searchsorted(sp, self._zd_m, side="right")
+        return [int(np.count_nonzero(dest == j)) for j in range(sp.shape[0] + 1)]
+
+    def zd_send_buffers(self):
+        return torch.from_numpy(self._zd_m.view(np.int64).copy()), torch.from_numpy(self._zd_ids.copy())
+
+    def zd_recv_buffers(self, nrecv):
+        self._zd_rk = torch.empty(int(nrecv), dtype=torch.int64)
+        self._zd_ri = torch.empty(int(nrecv), dtype=torch.int32)
+        return self._zd_rk, self._zd_ri
+
+    def zd_prepare(self, nrecv, sigma_off):
+        m = self._zd_rk.numpy().view(np.float64)
+        ids = self._zd_ri.numpy()
+        order = np.argsort(m, kind="stable")           # runs arrive in rank order: ties stay in row order
+        self._zd_cm, self._zd_cid = m[order].copy(), ids[order].copy()
+        self._zd_off = int(sigma_off)
+        sl = slice(self._zd_off, self._zd_off + int(nrecv))
+        self._zd_sa, self._zd_sb = self.sa[sl], self.sb[sl]
+        if self.wf == "ehrm":
+            return torch.from_numpy(zdist.ehrm_fvals(self._zd_sa, self._zd_sb, self.B, self.rho, self._zd_cm))
+        return torch.zeros(2, dtype=torch.float64)
+
+    def zd_pav(self, fvals_total):
+        self._zd_branch = -1
+        sg = self._zd_sa
+        loss = self.loss
+        if self.wf == "ehrm":
+            f = fvals_total.numpy()
+            self._zd_branch = 0 if f[0] <= f[1] else 1
+            sg = self._zd_sa if self._zd_branch == 0 else self._zd_sb
+        self._zd_chunk = zdist.RankChunk(loss, self.rho, self._zd_cm, sg)
+
+    def zd_bounds(self):
+        return torch.from_numpy(self._zd_chunk.bounds())
+
+    def zd_seam_setup(self, rank, world, level, bounds_all):
+        self._zd_rw = (rank, world, level)
+        self._zd_chunk.seam_setup(rank, world, level, bounds_all.numpy())
+
+    def zd_seam_propose(self, K, cand_all_prev, part_sum_prev):
+        rank, world, level = self._zd_rw
+        if part_sum_prev is not None:
+            self._zd_chunk.update(cand_all_prev.numpy(), part_sum_prev.numpy().reshape(-1, 3), K, world, level)
+        return torch.from_numpy(self._zd_chunk.propose(K))
+
+    def zd_seam_eval(self, K, cand_all):
+        rank, world, level = self._zd_rw
+        return torch.from_numpy(self._zd_chunk.evaluate(cand_all.numpy(), K, world, level).reshape(-1))
+
+    def zd_seam_sums(self, K, cand_all_prev, part_sum_prev, nseams):
+        rank, world, level = self._zd_rw
+        self._zd_chunk.update(cand_all_prev.numpy(), part_sum_prev.numpy().reshape(-1, 3), K, world, level)
+        return torch.from_numpy(self._zd_chunk.pooled_sums(nseams).reshape(-1))
+
+    def zd_seam_fill(self, sums_total, nseams):
+        self._zd_chunk.fill(sums_total.numpy().reshape(nseams, 3))
+
+    def zd_return_partition(self, nmax, world):
+        owner = self._zd_cid // nmax
+        order = np.argsort(owner, kind="stable")
+        self._zd_bid = self._zd_cid[order].copy()
+        self._zd_bu = self._zd_chunk.u[order].copy()
+        return [int(np.count_nonzero(owner == j)) for j in range(world)]
+
+    def zd_back_send(self):
+        return torch.from_numpy(self._zd_bid), torch.from_numpy(self._zd_bu)
+
+    def zd_back_recv(self, n):
+        self._zd_zi = torch.empty(int(n), dtype=torch.int32)
+        self._zd_zu = torch.empty(int(n), dtype=torch.float64)
+        return self._zd_zi, self._zd_zu
+
+    def zd_scatter(self, n):
+        ids = self._zd_zi.numpy().astype(np.int64) - self.off
+        u = self._zd_zu.numpy().copy()
+        if self._zd_branch == 0:
+            u = np.minimum(u, self.B)
+        elif self._zd_branch == 1:
+            u = np.maximum(u, self.B)
+        z = np.empty(self.n_local)
+        z[ids] = u
+        self.z = z

@@ -101,7 +101,7 @@ def _worker(rank, world, port, cfg, out):
         lo, cnt, _ = shard_rows(cfg["n"], world, rank)
         eng = NumpyEngine(X[lo:lo + cnt], y[lo:lo + cnt], cfg["n"], lo, cfg["wf"], cfg["loss"], cfg["reg"], cfg["l1"],
                           B=cfg.get("B"), args=cfg.get("args"))
-        drv = ShardedADMM(eng)
+        drv = ShardedADMM(eng, dist_z=cfg.get("dist_z", True))
         drv.setup_gram()
         hist = []
         for _ in range(cfg["iters"]):
@@ -120,11 +120,29 @@ def _worker(rank, world, port, cfg, out):
     dict(n=300, d=6, seed=6, wf="ehrm", B=-5, loss="binary_cross_entropy", reg=0.01, l1=False, iters=10),
 ], ids=["erm_l1", "superq_l2_uneven", "aorr_hinge", "ehrm"])
 def test_sharded_driver_world2_gloo_matches_single_process(cfg, tmp_path):
+    _check_sharded(cfg, 2, tmp_path)
+
+
+@pytest.mark.parametrize("world,cfg", [
+    (3, dict(n=501, d=9, seed=4, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, l1=False, iters=8)),
+    (4, dict(n=403, d=7, seed=5, wf="aorr", args=[0.2, 0.8], loss="hinge", reg=1e-4, l1=False, iters=8)),
+    (4, dict(n=300, d=6, seed=6, wf="ehrm", B=-5, loss="binary_cross_entropy", reg=0.01, l1=False, iters=8)),
+    (2, dict(n=501, d=9, seed=4, wf="extremile", args=[2.0], loss="binary_cross_entropy", reg=0.01, l1=False, iters=8,
+             dist_z=False)),
+], ids=["superq_world3", "aorr_world4", "ehrm_world4", "extremile_replicated_z"])
+def test_distributed_z_step_more_ranks(world, cfg, tmp_path):
+    """rank-weighted problems with the sorted order partitioned over 3 / 4 ranks (sample sort,
+    local PAV, merge tree over ranks: dist.py:_z_distributed on the NumPy engine), and the
+    replicated all-gather form."""
+    _check_sharded(cfg, world, tmp_path)
+
+
+def _check_sharded(cfg, world, tmp_path):
     import torch.multiprocessing as mp
     from oracle import admm, problems
     out = str(tmp_path / "r0.npz")
-    port = 29500 + (os.getpid() + hash(cfg["wf"])) % 2000
-    mp.spawn(_worker, args=(2, port, cfg, out), nprocs=2, join=True)
+    port = 29500 + (os.getpid() + hash(cfg["wf"]) + 7 * world) % 2000
+    mp.spawn(_worker, args=(world, port, cfg, out), nprocs=world, join=True)
     got = np.load(out)
     X, y = problems.make_problem(cfg["n"], cfg["d"], cfg["seed"])
     kw = dict(weight_function=cfg["wf"], loss=cfg["loss"], args=cfg.get("args"), B=cfg.get("B"))
