@@ -17,6 +17,8 @@ WEIGHT = {"erm": 0, "extremile": 1, "superquantile": 2, "esrm": 3, "aorr": 4, "a
 WSTEP_L1, WSTEP_L2, WSTEP_SMOOTH_L1 = 1, 2, 3
 STORAGE = {"f32": 0, "float32": 0, "f64": 1, "float64": 1}
 BUF_M, BUF_Q, BUF_RED, BUF_G, BUF_V, BUF_Z, BUF_LAM, BUF_W, BUF_COLSTATS = range(9)
+(BUF_ZD_SKEYS, BUF_ZD_SIDS, BUF_ZD_RKEYS, BUF_ZD_RIDS, BUF_ZD_SMALL, BUF_ZD_BIDS, BUF_ZD_BU, BUF_ZD_ZIDS,
+ BUF_ZD_ZU) = range(16, 25)
 KERNEL_GEMV, KERNEL_GEMVT, KERNEL_SWEEP_ERM = 0, 1, 2
 
 
@@ -83,6 +85,18 @@ SIGNATURES = {
     "rbl_fair_statistics": (C.c_int, [_P, _P, _P, C.c_double, _P]),
     "rbl_phase_m": (C.c_int, [_P]),
     "rbl_phase_z": (C.c_int, [_P, _P]),
+    "rbl_zd_sort_local": (C.c_int, [_P, C.c_int]),
+    "rbl_zd_partition": (C.c_int, [_P, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
+    "rbl_zd_prepare": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "rbl_zd_pav": (C.c_int, [_P, C.c_void_p]),
+    "rbl_zd_bounds": (C.c_int, [_P]),
+    "rbl_zd_seam_setup": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "rbl_zd_seam_propose": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_void_p]),
+    "rbl_zd_seam_eval": (C.c_int, [_P, C.c_int, C.c_void_p]),
+    "rbl_zd_seam_sums": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "rbl_zd_seam_fill": (C.c_int, [_P, C.c_void_p]),
+    "rbl_zd_return_partition": (C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
+    "rbl_zd_scatter": (C.c_int, [_P, C.c_int64]),
     "rbl_phase_q": (C.c_int, [_P]),
     "rbl_phase_w": (C.c_int, [_P]),
     "rbl_phase_dual": (C.c_int, [_P, C.c_int]),

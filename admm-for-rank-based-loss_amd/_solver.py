@@ -251,6 +251,48 @@ class Solver:
         _lib.check(self.lib.rbl_buffer(self._h, int(which), C.byref(p), C.byref(cnt)))
         return p.value, cnt.value
 
+    # ---- distributed z-step (include/rbl.h: rbl_zd_*; driver: dist.py:_z_distributed)
+    def zd_sort_local(self, nsamples):
+        _lib.check(self.lib.rbl_zd_sort_local(self._h, int(nsamples)))
+
+    def zd_partition(self, splitters_ptr, nparts):
+        out = (C.c_int64 * int(nparts))()
+        _lib.check(self.lib.rbl_zd_partition(self._h, C.c_void_p(splitters_ptr), int(nparts), out))
+        return [int(x) for x in out]
+
+    def zd_prepare(self, n_recv, sigma_off):
+        _lib.check(self.lib.rbl_zd_prepare(self._h, int(n_recv), int(sigma_off)))
+
+    def zd_pav(self, fvals_ptr):
+        _lib.check(self.lib.rbl_zd_pav(self._h, C.c_void_p(fvals_ptr)))
+
+    def zd_bounds(self):
+        _lib.check(self.lib.rbl_zd_bounds(self._h))
+
+    def zd_seam_setup(self, rank, world, level, bounds_all_ptr):
+        _lib.check(self.lib.rbl_zd_seam_setup(self._h, int(rank), int(world), int(level), C.c_void_p(bounds_all_ptr)))
+
+    def zd_seam_propose(self, K, cand_prev_ptr, part_prev_ptr):
+        _lib.check(self.lib.rbl_zd_seam_propose(self._h, int(K), C.c_void_p(cand_prev_ptr), C.c_void_p(part_prev_ptr)))
+
+    def zd_seam_eval(self, K, cand_all_ptr):
+        _lib.check(self.lib.rbl_zd_seam_eval(self._h, int(K), C.c_void_p(cand_all_ptr)))
+
+    def zd_seam_sums(self, K, cand_prev_ptr, part_prev_ptr, nseams):
+        _lib.check(self.lib.rbl_zd_seam_sums(self._h, int(K), C.c_void_p(cand_prev_ptr), C.c_void_p(part_prev_ptr),
+                                             int(nseams)))
+
+    def zd_seam_fill(self, sums_ptr):
+        _lib.check(self.lib.rbl_zd_seam_fill(self._h, C.c_void_p(sums_ptr)))
+
+    def zd_return_partition(self, nmax, world):
+        out = (C.c_int64 * int(world))()
+        _lib.check(self.lib.rbl_zd_return_partition(self._h, int(nmax), int(world), out))
+        return [int(x) for x in out]
+
+    def zd_scatter(self, n_back):
+        _lib.check(self.lib.rbl_zd_scatter(self._h, int(n_back)))
+
     def pending_reduce(self):
         m = C.c_int(0)
         _lib.check(self.lib.rbl_pending_reduce(self._h, C.byref(m)))

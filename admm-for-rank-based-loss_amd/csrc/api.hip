@@ -74,6 +74,17 @@ struct rbl_solver {
     // single-sweep erm iteration (sweep_erm.hip)
     bool fused_ok = false, z_ready = false, p_valid = false, p_pending = false, pred_valid = false, fused_ran = false;
     bool red_owned = false;
+    // distributed z-step (rbl_zd_*): this rank's chunk of the globally sorted order
+    double* zd_small = nullptr;      // samples | bounds | fvals | candidates | partial sums | seam sums
+    ZdSeam* zd_seam = nullptr;
+    int* zd_err = nullptr;
+    long long* zd_bounds_dev = nullptr;
+    u32* zd_zids = nullptr;          // row ids received back (n)
+    double *zd_locx_a = nullptr, *zd_chunk_a = nullptr, *zd_cph_a = nullptr, *zd_cpl_a = nullptr;
+    double *zd_locx_b = nullptr, *zd_chunk_b = nullptr, *zd_cph_b = nullptr, *zd_cpl_b = nullptr;
+    Prefix zpa{}, zpb{};
+    int64_t zd_n = 0, zd_off = 0;    // chunk length and its offset in the sorted order
+    int zd_world = 0;
     bool fuse_v = false;   // rank-weighted problems: v = D w fused with the lambda update (sweep_erm.hip, SE_VONLY)
     int pending_mask = 0;  // bit 0: the q part, bit 1: the residual part of the exchange buffer awaits a sum over ranks
     double *z_next = nullptr, *p = nullptr, *p_alt = nullptr, *pred = nullptr;
@@ -373,6 +384,9 @@ int rbl_destroy(rbl_solver* h) {
     if (h->red_owned) dev_free(h->red);
     dev_free(h->red2); dev_free(h->ysign); dev_free(h->colstats); dev_free(h->z_next); dev_free(h->p); dev_free(h->p_alt); dev_free(h->pred);
     if (h->hstat) (void)hipHostFree(h->hstat);
+    dev_free(h->zd_small); dev_free(h->zd_seam); dev_free(h->zd_err); dev_free(h->zd_bounds_dev); dev_free(h->zd_zids);
+    dev_free(h->zd_locx_a); dev_free(h->zd_chunk_a); dev_free(h->zd_cph_a); dev_free(h->zd_cpl_a);
+    dev_free(h->zd_locx_b); dev_free(h->zd_chunk_b); dev_free(h->zd_cph_b); dev_free(h->zd_cpl_b);
     free_sort(h->sw);
     free_pav(h->pw);
     dev_free(h->locx_a); dev_free(h->chunk_a); dev_free(h->cph_a); dev_free(h->cpl_a);
@@ -1224,6 +1238,203 @@ int rbl_accuracy(rbl_solver* h, const double* w, double threshold, double* out) 
     return RBL_OK;
 }
 
+
+// ================================================================== distributed z-step
+// Rank-weighted problems on several GPUs: the driver (dist.py: _z_distributed)
+// calls these between its collectives; oracle/zdist.py restates every step on the CPU.
+// Layout of RBL_BUF_ZD_SMALL (doubles): [0,256) samples | [256,259) bounds | [260,262) EHRM
+// fvals | [320,384) candidates | [512, 512+3*4096) partial sums | [12800+..) seam sums.
+namespace {
+constexpr int ZD_SMALL_DOUBLES = 16384;
+constexpr int ZD_OFF_SAMPLES = 0, ZD_OFF_BOUNDS = 256, ZD_OFF_FV = 260, ZD_OFF_CAND = 320, ZD_OFF_PART = 512,
+              ZD_OFF_SUMS = 512 + 3 * 4096;
+constexpr int ZD_MAX_CAND = 4096;   // world * K
+
+int zd_ensure(rbl_solver* h) {
+    if (h->zd_small) return RBL_OK;
+    if (!h->sorted_path || h->cfg.objective_only) {
+        rbl_set_error("distributed z-step: only for rank-weighted solver handles");
+        return RBL_ERR_STATE;
+    }
+    RBL_TRY(dev_alloc(&h->zd_small, ZD_SMALL_DOUBLES));
+    RBL_TRY(dev_alloc(&h->zd_seam, 1));
+    RBL_TRY(dev_alloc(&h->zd_err, 1));
+    RBL_TRY(dev_alloc(&h->zd_bounds_dev, 80));
+    RBL_TRY(dev_alloc(&h->zd_zids, (size_t)h->n));
+    RBL_TRY(alloc_prefix(&h->zd_locx_a, &h->zd_chunk_a, &h->zd_cph_a, &h->zd_cpl_a, h->nt));
+    h->zpa = Prefix{h->zd_locx_a, h->zd_cph_a, h->zd_cpl_a};
+    h->zpb = h->zpa;
+    if (h->cfg.weight_function == RBL_W_EHRM) {
+        RBL_TRY(alloc_prefix(&h->zd_locx_b, &h->zd_chunk_b, &h->zd_cph_b, &h->zd_cpl_b, h->nt));
+        h->zpb = Prefix{h->zd_locx_b, h->zd_cph_b, h->zd_cpl_b};
+    }
+    RBL_HIP(hipMemsetAsync(h->zd_err, 0, sizeof(int), h->stream));
+    return RBL_OK;
+}
+}  // namespace
+
+int rbl_zd_sort_local(rbl_solver* h, int nsamples) {
+    RBL_ENTER_ITER(h);
+    RBL_TRY(zd_ensure(h));
+    if (nsamples < 1 || nsamples > 256) {
+        rbl_set_error("zd_sort_local: 1..256 samples");
+        return RBL_ERR_INVALID;
+    }
+    hipStream_t s = h->stream;
+    // keys of the local m, payload = GLOBAL row id
+    RBL_TRY(launch_keys_from_m(h->n, h->m, h->sw.keys[0], h->sw.vals[0], s));
+    if (h->off != 0) RBL_TRY(launch_add_u32(h->n, h->sw.vals[0], (u32)h->off, s));
+    RBL_TRY(launch_radix_sort(h->sw, h->n, true, s));
+    RBL_TRY(launch_zd_sample(h->sw.keys[0], h->n, nsamples, h->zd_small + ZD_OFF_SAMPLES, s));
+    return RBL_OK;
+}
+
+int rbl_zd_partition(rbl_solver* h, const void* splitters_dev, int nparts, int64_t* send_counts) {
+    RBL_ENTER_ITER(h);
+    if (nparts < 1 || nparts > 64 || !send_counts) return RBL_ERR_INVALID;
+    long long hb[64];
+    if (nparts > 1) {
+        RBL_TRY(launch_zd_split_bounds(h->sw.keys[0], h->n, (const double*)splitters_dev, nparts - 1, h->zd_bounds_dev,
+                                       h->stream));
+        RBL_HIP(hipMemcpyAsync(hb, h->zd_bounds_dev, sizeof(long long) * (nparts - 1), hipMemcpyDeviceToHost, h->stream));
+    }
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    long long prev = 0;
+    for (int j = 0; j < nparts; ++j) {
+        long long b = j == nparts - 1 ? (long long)h->n : hb[j];
+        if (b < prev) b = prev;   // splitters are sorted; equal splitters give empty parts
+        send_counts[j] = b - prev;
+        prev = b;
+    }
+    h->zd_world = nparts;
+    return RBL_OK;
+}
+
+// the received (key, id) pairs are in RBL_BUF_ZD_RKEYS / RIDS: sort the chunk, sorted m, prefix
+// sums of m and of the chunk's slice of sigma; EHRM: this chunk's two singleton-stage sums
+int rbl_zd_prepare(rbl_solver* h, int64_t nrecv, int64_t sigma_off) {
+    RBL_ENTER_ITER(h);
+    RBL_TRY(zd_ensure(h));
+    if (nrecv < 0 || sigma_off < 0 || sigma_off + nrecv > h->nt) {
+        rbl_set_error("zd_prepare: chunk [%lld, %lld) outside the %lld sorted positions", (long long)sigma_off,
+                      (long long)(sigma_off + nrecv), (long long)h->nt);
+        return RBL_ERR_INVALID;
+    }
+    hipStream_t s = h->stream;
+    // the received pairs move to the sort's input buffers (the pointers behind the typed views stay put)
+    RBL_HIP(hipMemcpyAsync(h->sw.keys[0], h->sw.keys[1], sizeof(u64) * (size_t)nrecv, hipMemcpyDeviceToDevice, s));
+    RBL_HIP(hipMemcpyAsync(h->sw.vals[0], h->sw.vals[1], sizeof(u32) * (size_t)nrecv, hipMemcpyDeviceToDevice, s));
+    h->zd_n = nrecv;
+    h->zd_off = sigma_off;
+    RBL_TRY(launch_radix_sort(h->sw, nrecv, true, s));   // runs arrive in rank order: stable => ties in row order
+    RBL_TRY(launch_unflip_keys(nrecv, h->sw.keys[0], h->pw.ms, s));
+    RBL_TRY(launch_prefix(h->pw.ms, nrecv, h->pw.locx_m, h->pw.chunk_m, h->pw.cph_m, h->pw.cpl_m, s));
+    RBL_TRY(launch_prefix(h->sigma_a + sigma_off, nrecv, h->zd_locx_a, h->zd_chunk_a, h->zd_cph_a, h->zd_cpl_a, s));
+    const bool ehrm = h->cfg.weight_function == RBL_W_EHRM;
+    double* fv = h->zd_small + ZD_OFF_FV;
+    if (ehrm) {
+        RBL_TRY(launch_prefix(h->sigma_b + sigma_off, nrecv, h->zd_locx_b, h->zd_chunk_b, h->zd_cph_b, h->zd_cpl_b, s));
+        RBL_TRY(launch_ehrm_fvals(nrecv, h->sigma_a + sigma_off, h->sigma_b + sigma_off, h->cfg.B, h->step_rho, h->pw.ms,
+                                  h->pw.partials, fv, s));
+    } else {
+        RBL_HIP(hipMemsetAsync(fv, 0, 2 * sizeof(double), s));
+    }
+    return RBL_OK;
+}
+
+int rbl_zd_pav(rbl_solver* h, const void* fvals_total_dev) {
+    RBL_ENTER_ITER(h);
+    hipStream_t s = h->stream;
+    const bool ehrm = h->cfg.weight_function == RBL_W_EHRM;
+    if (ehrm) RBL_TRY(launch_ehrm_pick((const double*)fvals_total_dev, h->pw.branch, s));
+    const Prefix pm{h->pw.locx_m, h->pw.cph_m, h->pw.cpl_m};
+    RBL_TRY(launch_pav_tree(h->cfg.loss, h->zd_n, h->step_rho, h->pw.ms, h->sigma_a + h->zd_off, h->sigma_b + h->zd_off,
+                            h->pw.u, h->zpa, h->zpb, pm, ehrm ? h->pw.branch : nullptr, h->pw.recs, h->pw.counters, s));
+    return RBL_OK;
+}
+
+int rbl_zd_bounds(rbl_solver* h) {
+    RBL_ENTER_ITER(h);
+    return launch_zd_bounds(h->pw.u, h->zd_n, h->zd_small + ZD_OFF_BOUNDS, h->stream);
+}
+
+int rbl_zd_seam_setup(rbl_solver* h, int rank, int world, int level, const void* bounds_all_dev) {
+    RBL_ENTER_ITER(h);
+    if (world < 1 || world > 64 || rank < 0 || rank >= world || level < 1) return RBL_ERR_INVALID;
+    h->zd_world = world;
+    return launch_zd_seam_setup(rank, world, level, (const double*)bounds_all_dev, h->zd_n, h->zd_seam, h->stream);
+}
+
+int rbl_zd_seam_propose(rbl_solver* h, int K, const void* cand_all_prev, const void* part_sum_prev) {
+    RBL_ENTER_ITER(h);
+    if (K < 1 || K > 64 || K * h->zd_world > ZD_MAX_CAND) return RBL_ERR_INVALID;
+    return launch_zd_update_propose(h->cfg.loss, h->zd_seam, h->pw.u, K, h->zd_world, (const double*)cand_all_prev,
+                                    (const double*)part_sum_prev, h->step_rho, h->zd_small + ZD_OFF_CAND, h->stream);
+}
+
+int rbl_zd_seam_eval(rbl_solver* h, int K, const void* cand_all_dev) {
+    RBL_ENTER_ITER(h);
+    if (K < 1 || K > 64 || K * h->zd_world > ZD_MAX_CAND) return RBL_ERR_INVALID;
+    const bool ehrm = h->cfg.weight_function == RBL_W_EHRM;
+    const Prefix pm{h->pw.locx_m, h->pw.cph_m, h->pw.cpl_m};
+    return launch_zd_eval(h->zd_seam, h->pw.u, h->zpa, h->zpb, pm, ehrm ? h->pw.branch : nullptr, K, h->zd_world,
+                          (const double*)cand_all_dev, h->zd_small + ZD_OFF_PART, h->stream);
+}
+
+int rbl_zd_seam_sums(rbl_solver* h, int K, const void* cand_all_prev, const void* part_sum_prev, int nseams) {
+    RBL_ENTER_ITER(h);
+    if (nseams < 1 || nseams > 32) return RBL_ERR_INVALID;
+    RBL_TRY(launch_zd_update_propose(h->cfg.loss, h->zd_seam, h->pw.u, K, h->zd_world, (const double*)cand_all_prev,
+                                     (const double*)part_sum_prev, h->step_rho, nullptr, h->stream));
+    const bool ehrm = h->cfg.weight_function == RBL_W_EHRM;
+    const Prefix pm{h->pw.locx_m, h->pw.cph_m, h->pw.cpl_m};
+    return launch_zd_pooled(h->zd_seam, h->zpa, h->zpb, pm, ehrm ? h->pw.branch : nullptr, nseams,
+                            h->zd_small + ZD_OFF_SUMS, h->zd_err, h->stream);
+}
+
+int rbl_zd_seam_fill(rbl_solver* h, const void* sums_total_dev) {
+    RBL_ENTER_ITER(h);
+    return launch_zd_fill(h->cfg.loss, h->zd_seam, (const double*)sums_total_dev, h->step_rho, h->pw.u, h->zd_n, h->stream);
+}
+
+// sort the chunk's (row id, u) by row id: contiguous per owner rank (rows are sharded in
+// blocks of nmax); counts[r] = how many go back to rank r.  RBL_BUF_ZD_BIDS / BU hold them.
+int rbl_zd_return_partition(rbl_solver* h, int64_t nmax, int world, int64_t* counts) {
+    RBL_ENTER_ITER(h);
+    if (world < 1 || world > 64 || nmax < 1 || !counts) return RBL_ERR_INVALID;
+    hipStream_t s = h->stream;
+    int herr = 0;
+    RBL_TRY(launch_zd_ids_to_keys(h->zd_n, h->sw.vals[0], h->sw.keys[0], h->sw.vals[0], s));
+    RBL_TRY(launch_radix_sort(h->sw, h->zd_n, true, s));
+    RBL_TRY(launch_zd_owner_bounds(h->sw.keys[0], h->zd_n, nmax, world, h->zd_bounds_dev, s));
+    RBL_TRY(launch_zd_gather_back(h->zd_n, h->sw.keys[0], h->sw.vals[0], h->pw.u, h->sw.vals[1], (double*)h->sw.keys[1], s));
+    long long hb[65];
+    RBL_HIP(hipMemcpyAsync(hb, h->zd_bounds_dev, sizeof(long long) * (world + 1), hipMemcpyDeviceToHost, s));
+    RBL_HIP(hipMemcpyAsync(&herr, h->zd_err, sizeof(int), hipMemcpyDeviceToHost, s));
+    RBL_HIP(hipStreamSynchronize(s));
+    if (herr) {
+        RBL_HIP(hipMemsetAsync(h->zd_err, 0, sizeof(int), s));
+        rbl_set_error("distributed z-step: a seam search did not finish within its rounds");
+        return RBL_ERR_STATE;
+    }
+    for (int r = 0; r < world; ++r) counts[r] = hb[r + 1] - hb[r];
+    return RBL_OK;
+}
+
+// rows received back in RBL_BUF_ZD_ZIDS / ZU: z, c = z + lambda/rho (algorithms.py:103-104, :192)
+int rbl_zd_scatter(rbl_solver* h, int64_t n_back) {
+    RBL_ENTER_ITER(h);
+    if (n_back != h->n) {
+        rbl_set_error("zd_scatter: %lld rows came back, %lld are local", (long long)n_back, (long long)h->n);
+        return RBL_ERR_STATE;
+    }
+    const bool ehrm = h->cfg.weight_function == RBL_W_EHRM;
+    RBL_TRY(launch_zd_scatter(n_back, h->zd_zids, h->m, ehrm ? h->pw.branch : nullptr, h->cfg.B, ehrm ? 1 : 0, h->step_rho,
+                              h->lam, h->z, h->c, h->off, h->n, h->stream));
+    if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[1], h->stream));
+    return RBL_OK;
+}
+
 int rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles) {
     RBL_ENTER(h);
     void* p = nullptr;
@@ -1238,6 +1449,16 @@ int rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles) {
         case RBL_BUF_LAM: p = h->lam; cnt = h->n; break;
         case RBL_BUF_W: p = h->w; cnt = h->ld; break;
         case 8: p = h->colstats; cnt = 2 * h->ld; break;  // RBL_BUF_COLSTATS
+        // distributed z-step: typed views (element counts; int64 / int32 / double as rbl.h says)
+        case RBL_BUF_ZD_SKEYS: p = h->sorted_path ? h->sw.keys[0] : nullptr; cnt = h->n; break;
+        case RBL_BUF_ZD_SIDS: p = h->sorted_path ? h->sw.vals[0] : nullptr; cnt = h->n; break;
+        case RBL_BUF_ZD_RKEYS: p = h->sorted_path ? h->sw.keys[1] : nullptr; cnt = h->nt; break;
+        case RBL_BUF_ZD_RIDS: p = h->sorted_path ? h->sw.vals[1] : nullptr; cnt = h->nt; break;
+        case RBL_BUF_ZD_SMALL: RBL_TRY(zd_ensure(h)); p = h->zd_small; cnt = ZD_SMALL_DOUBLES; break;
+        case RBL_BUF_ZD_BIDS: p = h->sorted_path ? h->sw.vals[1] : nullptr; cnt = h->nt; break;
+        case RBL_BUF_ZD_BU: p = h->sorted_path ? h->sw.keys[1] : nullptr; cnt = h->nt; break;
+        case RBL_BUF_ZD_ZIDS: RBL_TRY(zd_ensure(h)); p = h->zd_zids; cnt = h->n; break;
+        case RBL_BUF_ZD_ZU: p = h->m; cnt = h->n; break;
         default: rbl_set_error("unknown buffer id %d", which); return RBL_ERR_INVALID;
     }
     if (dev_ptr) *dev_ptr = p;

@@ -506,6 +506,269 @@ __global__ void k_scatter_z(long long n, const double* __restrict__ u, const u32
     }
 }
 
+
+// ================================================================ merge tree over RANKS
+// Distributed z-step (several GPUs, rank weights): every rank owns a contiguous range of the
+// globally sorted order and has solved it (launch_pav_tree above).  The chunks are joined by a
+// merge tree over ranks; the seam rule is seam_merge()'s, but a probe of Psi(t) needs only
+// (count, sum sigma, sum m) of {left: u > t} / {right: u < t}, which every rank computes on its
+// own chunk (k_zd_eval) and the host sums over ranks (one small all-reduce).  The extents are
+// found by a K-ary search: per round every rank proposes K of its still undecided u values
+// (k_zd_update_propose), all candidates of a seam are evaluated together and every rank narrows
+// its undecided index range [lo, hi) with the signs.  CPU restatement: oracle/zdist.py.
+__device__ inline long long zd_upper_gt(const double* __restrict__ u, long long n, double t) {
+    long long lo = 0, hi = n;   // first i with u[i] > t
+    while (lo < hi) {
+        const long long mid = lo + ((hi - lo) >> 1);
+        if (u[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+__device__ inline long long zd_lower_ge(const double* __restrict__ u, long long n, double t) {
+    long long lo = 0, hi = n;   // first i with u[i] >= t
+    while (lo < hi) {
+        const long long mid = lo + ((hi - lo) >> 1);
+        if (u[mid] >= t) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ void k_zd_sample(const u64* __restrict__ keys, long long n, int ns, double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ns) return;
+    double r = __longlong_as_double(0x7ff8000000000000ll);   // NaN = no sample
+    if (n > ns) r = rbl::unflip_key(keys[((long long)(j + 1) * n) / (ns + 1)]);
+    else if (j < n) r = rbl::unflip_key(keys[j]);
+    out[j] = r;
+}
+
+// bounds[j] = first sorted position whose key is >= the key of splitter j
+__global__ void k_zd_split_bounds(const u64* __restrict__ keys, long long n, const double* __restrict__ split,
+                                  int nsplit, long long* __restrict__ bounds) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nsplit) return;
+    const u64 key = rbl::flip_key(split[j]);
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] >= key) hi = mid; else lo = mid + 1;
+    }
+    bounds[j] = lo;
+}
+
+__global__ void k_zd_bounds(const double* __restrict__ u, long long n, double* __restrict__ out3) {
+    if (threadIdx.x || blockIdx.x) return;
+    out3[0] = n > 0 ? u[0] : 0.0;
+    out3[1] = n > 0 ? u[n - 1] : 0.0;
+    out3[2] = (double)n;
+}
+
+// oracle/zdist.py: seam_of + RankChunk.seam_setup
+__global__ void k_zd_seam_setup(int rank, int world, int level, const double* __restrict__ bounds_all, long long n,
+                                ZdSeam* __restrict__ st) {
+    if (threadIdx.x || blockIdx.x) return;
+    ZdSeam s;
+    s.active = 0; s.k = 0; s.side = 0; s.a0 = 0; s.b1 = 0; s.lo = 0; s.hi = n; s.n = n; s.x = 0.0; s.cnt = 0.0;
+    const int half = 1 << (level - 1);
+    const int k = (rank / half) / 2;
+    const int a0 = 2 * k * half, b0 = a0 + half;
+    if (b0 < world) {
+        const int b1 = (b0 + half < world) ? b0 + half : world;
+        int last_left = -1, first_right = -1;
+        for (int r = a0; r < b0; ++r)
+            if (bounds_all[3 * r + 2] > 0.0) last_left = r;
+        for (int r = b1 - 1; r >= b0; --r)
+            if (bounds_all[3 * r + 2] > 0.0) first_right = r;
+        if (last_left >= 0 && first_right >= 0 &&
+            bounds_all[3 * last_left + 1] > bounds_all[3 * first_right + 0]) {   // pav.py:105: strict decrease only
+            s.active = 1;
+            s.k = k;
+            s.side = rank < b0 ? 0 : 1;
+            s.a0 = a0;
+            s.b1 = b1;
+        }
+    }
+    *st = s;
+}
+
+template <int LOSS>
+__device__ inline double zd_psi(double cnt, double A, double M, double rho, double t) {
+    if (!(cnt > 0.0)) return 0.0;
+    if (LOSS == 0) return A * rbl::sigmoid1(t) + rho * (cnt * t - M);
+    return t - block_value<1>(A, M, cnt, rho);
+}
+
+// narrow [lo, hi) with the summed (count, sum sigma, sum m) of the previous round's candidates
+// (oracle/zdist.py: RankChunk.update), then propose K new candidates (RankChunk.propose)
+template <int LOSS>
+__global__ __launch_bounds__(256) void k_zd_update_propose(ZdSeam* __restrict__ st, const double* __restrict__ u, int K,
+                                                            int world, const double* __restrict__ cand_prev,
+                                                            const double* __restrict__ part_prev, double rho,
+                                                            double* __restrict__ cand_out) {
+    __shared__ long long s_lo, s_hi;
+    const ZdSeam s = *st;
+    if (threadIdx.x == 0) {
+        s_lo = s.lo;
+        s_hi = s.hi;
+    }
+    __syncthreads();
+    if (s.active && cand_prev && part_prev) {
+        for (int c = threadIdx.x; c < world * K; c += 256) {
+            const double t = cand_prev[c];
+            const int r = c / K;
+            if (t != t || r < s.a0 || r >= s.b1) continue;
+            const double sg = zd_psi<LOSS>(part_prev[3 * c], part_prev[3 * c + 1], part_prev[3 * c + 2], rho, t);
+            if (s.side == 0) {   // s* = first left position with Psi(u[i]) > 0
+                if (sg > 0.0) atomicMin(&s_hi, zd_lower_ge(u, s.n, t));
+                else atomicMax(&s_lo, zd_upper_gt(u, s.n, t));
+            } else {             // e* = last right position with Psi(u[j]) < 0
+                if (sg < 0.0) atomicMax(&s_lo, zd_upper_gt(u, s.n, t));
+                else atomicMin(&s_hi, zd_lower_ge(u, s.n, t));
+            }
+        }
+    }
+    __syncthreads();
+    long long lo = s_lo, hi = s_hi;
+    if (hi < lo) hi = lo;
+    if (threadIdx.x == 0) {
+        st->lo = lo;
+        st->hi = hi;
+    }
+    if (cand_out && threadIdx.x < K) {
+        const int j = threadIdx.x;
+        double r = __longlong_as_double(0x7ff8000000000000ll);
+        const long long sz = hi - lo;
+        if (s.active && sz > 0) {
+            if (sz <= K) {
+                if (j < sz) r = u[lo + j];
+            } else {
+                r = u[lo + ((long long)(j + 1) * sz) / (K + 1)];
+            }
+        }
+        cand_out[j] = r;
+    }
+}
+
+// partial (count, sum sigma, sum m) of this rank for every candidate of its seam
+__global__ __launch_bounds__(256) void k_zd_eval(const ZdSeam* __restrict__ st, const double* __restrict__ u, Prefix pa_,
+                                                  Prefix pb_, Prefix pm, const int* __restrict__ branch, int K, int world,
+                                                  const double* __restrict__ cand_all, double* __restrict__ part) {
+    const ZdSeam s = *st;
+    const Prefix pa = (branch && *branch) ? pb_ : pa_;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < world * K; c += gridDim.x * 256) {
+        double cnt = 0.0, A = 0.0, M = 0.0;
+        const double t = cand_all[c];
+        const int r = c / K;
+        if (s.active && t == t && r >= s.a0 && r < s.b1) {
+            long long b, e;
+            if (s.side == 0) {   // left group: positions with u > t (a suffix)
+                b = zd_upper_gt(u, s.n, t);
+                e = s.n;
+            } else {             // right group: positions with u < t (a prefix)
+                b = 0;
+                e = zd_lower_ge(u, s.n, t);
+            }
+            if (e > b) {
+                cnt = (double)(e - b);
+                A = range_sum(pa, b, e);
+                M = range_sum(pm, b, e);
+            }
+        }
+        part[3 * c] = cnt;
+        part[3 * c + 1] = A;
+        part[3 * c + 2] = M;
+    }
+}
+
+// (count, sum sigma, sum m) of this rank's pooled positions into its seam's slot
+__global__ void k_zd_pooled(const ZdSeam* __restrict__ st, Prefix pa_, Prefix pb_, Prefix pm, const int* __restrict__ branch,
+                            int nseams, double* __restrict__ sums, int* __restrict__ err) {
+    const int i = threadIdx.x;
+    if (i < 3 * nseams) sums[i] = 0.0;
+    __syncthreads();
+    if (i != 0) return;
+    const ZdSeam s = *st;
+    if (!s.active) return;
+    if (s.lo != s.hi) {
+        *err = 1;   // the search did not finish: more rounds needed (host raises)
+        return;
+    }
+    const Prefix pa = (branch && *branch) ? pb_ : pa_;
+    const long long b = s.side == 0 ? s.hi : 0, e = s.side == 0 ? s.n : s.lo;
+    if (e > b) {
+        sums[3 * s.k] = (double)(e - b);
+        sums[3 * s.k + 1] = range_sum(pa, b, e);
+        sums[3 * s.k + 2] = range_sum(pm, b, e);
+    }
+}
+
+template <int LOSS>
+__global__ void k_zd_fill_value(ZdSeam* __restrict__ st, const double* __restrict__ sums_total, double rho) {
+    if (threadIdx.x || blockIdx.x) return;
+    ZdSeam s = *st;
+    s.cnt = 0.0;
+    if (s.active) {
+        const double cnt = sums_total[3 * s.k], A = sums_total[3 * s.k + 1], M = sums_total[3 * s.k + 2];
+        if (cnt > 0.0) {
+            s.cnt = cnt;
+            s.x = block_value<LOSS>(A, M, cnt, rho);
+        }
+    }
+    *st = s;
+}
+
+__global__ void k_zd_fill_range(const ZdSeam* __restrict__ st, double* __restrict__ u) {
+    const ZdSeam s = *st;
+    if (!s.active || !(s.cnt > 0.0)) return;
+    const long long b = s.side == 0 ? s.hi : 0, e = s.side == 0 ? s.n : s.lo;
+    for (long long i = b + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (long long)gridDim.x * blockDim.x)
+        u[i] = s.x;
+}
+
+// return path: keys = row ids (for the sort by owner), vals = chunk positions
+__global__ void k_zd_ids_to_keys(long long n, const u32* ids, u64* __restrict__ keys, u32* pos) {   // pos may alias ids
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        keys[i] = (u64)ids[i];
+        pos[i] = (u32)i;
+    }
+}
+__global__ void k_zd_gather_back(long long n, const u64* __restrict__ keys_sorted, const u32* __restrict__ pos,
+                                 const double* __restrict__ u, u32* __restrict__ out_ids, double* __restrict__ out_u) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        out_ids[i] = (u32)keys_sorted[i];
+        out_u[i] = u[pos[i]];
+    }
+}
+__global__ void k_zd_owner_bounds(const u64* __restrict__ keys_sorted, long long n, long long nmax, int world,
+                                  long long* __restrict__ bounds) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;   // bounds[j] = first position with id >= j * nmax
+    if (j > world) return;
+    const u64 key = (u64)j * (u64)nmax;
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = lo + ((hi - lo) >> 1);
+        if (keys_sorted[mid] >= key) hi = mid; else lo = mid + 1;
+    }
+    bounds[j] = j == world ? n : lo;
+}
+
+// z[id - off] = clip(u); c = z + lambda/rho  (algorithms.py:103-104 and :192), rows received back
+__global__ void k_zd_scatter(long long n, const u32* __restrict__ ids, const double* __restrict__ uu,
+                             const int* __restrict__ branch, double B, int has_B, double rho,
+                             const double* __restrict__ lam, double* __restrict__ z, double* __restrict__ c,
+                             long long off, long long nloc) {
+    const int br = (has_B && branch) ? *branch : -1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long l = (long long)ids[i] - off;
+        if (l < 0 || l >= nloc) continue;
+        double x = uu[i];
+        if (br == 0) x = fmin(x, B);
+        else if (br == 1) x = fmax(x, B);
+        z[l] = x;
+        if (c) c[l] = x + lam[l] / rho;
+    }
+}
+
 }  // namespace
 
 int64_t pav_num_chunks(int64_t n) { return n / PAV_CHUNK + 1; }
@@ -543,6 +806,34 @@ int launch_ehrm_branch(int64_t n, const double* sa, const double* sb, double B, 
     const int nb = reduce_blocks();
     hipLaunchKernelGGL(k_ehrm_fvals, dim3(nb), dim3(PV_THREADS), 0, s, (long long)n, sa, sb, B, rho, ms, partials);
     hipLaunchKernelGGL(k_ehrm_pick, dim3(1), dim3(256), 0, s, partials, nb, forced, branch);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+// the two singleton-stage sums of this chunk alone -> out2 (summed over ranks by the caller)
+int launch_ehrm_fvals(int64_t n, const double* sa, const double* sb, double B, double rho, const double* ms,
+                      double* partials, double* out2, hipStream_t s) {
+    const int nb = reduce_blocks();
+    hipLaunchKernelGGL(k_ehrm_fvals, dim3(nb), dim3(PV_THREADS), 0, s, (long long)n, sa, sb, B, rho, ms, partials);
+    RBL_HIP(hipGetLastError());
+    return launch_sum_partials(partials, nb, 2, out2, s);
+}
+// branch from the sums over all ranks (PAV_cpt.py:225-226)
+int launch_ehrm_pick(const double* fvals_total, int* branch, hipStream_t s) {
+    hipLaunchKernelGGL(k_ehrm_pick, dim3(1), dim3(256), 0, s, fvals_total, 1, -1, branch);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+namespace {
+__global__ void k_add_u32(long long n, u32* __restrict__ x, u32 add) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        x[i] += add;
+}
+}  // namespace
+int launch_add_u32(int64_t n, u32* x, u32 add, hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    hipLaunchKernelGGL(k_add_u32, dim3(pv_grid(n)), dim3(256), 0, s, (long long)n, x, add);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }
@@ -592,6 +883,85 @@ int launch_scatter_z(int64_t n, const double* u, const u32* perm, const int* bra
     if (n <= 0) return RBL_OK;
     hipLaunchKernelGGL(k_scatter_z, dim3(pv_grid(n)), dim3(256), 0, s, (long long)n, u, perm, branch, B, has_B, rho,
                        lam, z, c, (long long)off, (long long)nloc);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+// ---------------------------------------------------------------- distributed z-step launchers
+int launch_zd_sample(const u64* keys, int64_t n, int ns, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_zd_sample, dim3((ns + 255) / 256), dim3(256), 0, s, keys, (long long)n, ns, out);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zd_split_bounds(const u64* keys, int64_t n, const double* split, int nsplit, long long* bounds, hipStream_t s) {
+    if (nsplit <= 0) return RBL_OK;
+    hipLaunchKernelGGL(k_zd_split_bounds, dim3((nsplit + 63) / 64), dim3(64), 0, s, keys, (long long)n, split, nsplit, bounds);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zd_bounds(const double* u, int64_t n, double* out3, hipStream_t s) {
+    hipLaunchKernelGGL(k_zd_bounds, dim3(1), dim3(64), 0, s, u, (long long)n, out3);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zd_seam_setup(int rank, int world, int level, const double* bounds_all, int64_t n, ZdSeam* st, hipStream_t s) {
+    hipLaunchKernelGGL(k_zd_seam_setup, dim3(1), dim3(64), 0, s, rank, world, level, bounds_all, (long long)n, st);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zd_update_propose(int loss, ZdSeam* st, const double* u, int K, int world, const double* cand_prev,
+                             const double* part_prev, double rho, double* cand_out, hipStream_t s) {
+    if (loss == RBL_LOSS_BCE)
+        hipLaunchKernelGGL(k_zd_update_propose<0>, dim3(1), dim3(256), 0, s, st, u, K, world, cand_prev, part_prev, rho, cand_out);
+    else
+        hipLaunchKernelGGL(k_zd_update_propose<1>, dim3(1), dim3(256), 0, s, st, u, K, world, cand_prev, part_prev, rho, cand_out);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zd_eval(const ZdSeam* st, const double* u, Prefix pa, Prefix pb, Prefix pm, const int* branch, int K, int world,
+                   const double* cand_all, double* part, hipStream_t s) {
+    const int total = K * world;
+    hipLaunchKernelGGL(k_zd_eval, dim3((total + 255) / 256), dim3(256), 0, s, st, u, pa, pb, pm, branch, K, world, cand_all, part);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zd_pooled(const ZdSeam* st, Prefix pa, Prefix pb, Prefix pm, const int* branch, int nseams, double* sums, int* err,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_zd_pooled, dim3(1), dim3(256), 0, s, st, pa, pb, pm, branch, nseams, sums, err);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zd_fill(int loss, ZdSeam* st, const double* sums_total, double rho, double* u, int64_t n, hipStream_t s) {
+    if (loss == RBL_LOSS_BCE) hipLaunchKernelGGL(k_zd_fill_value<0>, dim3(1), dim3(64), 0, s, st, sums_total, rho);
+    else hipLaunchKernelGGL(k_zd_fill_value<1>, dim3(1), dim3(64), 0, s, st, sums_total, rho);
+    hipLaunchKernelGGL(k_zd_fill_range, dim3(pv_grid(n > 0 ? n : 1, 256, 4096)), dim3(256), 0, s, st, u);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zd_ids_to_keys(int64_t n, const u32* ids, u64* keys, u32* pos, hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    hipLaunchKernelGGL(k_zd_ids_to_keys, dim3(pv_grid(n)), dim3(256), 0, s, (long long)n, ids, keys, pos);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zd_gather_back(int64_t n, const u64* keys_sorted, const u32* pos, const double* u, u32* out_ids, double* out_u,
+                          hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    hipLaunchKernelGGL(k_zd_gather_back, dim3(pv_grid(n)), dim3(256), 0, s, (long long)n, keys_sorted, pos, u, out_ids, out_u);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zd_owner_bounds(const u64* keys_sorted, int64_t n, int64_t nmax, int world, long long* bounds, hipStream_t s) {
+    hipLaunchKernelGGL(k_zd_owner_bounds, dim3((world + 64) / 64), dim3(64), 0, s, keys_sorted, (long long)n, (long long)nmax,
+                       world, bounds);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zd_scatter(int64_t n, const u32* ids, const double* uu, const int* branch, double B, int has_B, double rho,
+                      const double* lam, double* z, double* c, int64_t off, int64_t nloc, hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    hipLaunchKernelGGL(k_zd_scatter, dim3(pv_grid(n)), dim3(256), 0, s, (long long)n, ids, uu, branch, B, has_B, rho, lam, z,
+                       c, (long long)off, (long long)nloc);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

@@ -137,6 +137,33 @@ int launch_pav_tree(int loss, int64_t n, double rho, const double* ms, const dou
                     Prefix pa, Prefix pb, Prefix pm, const int* branch, SeamRec* recs, u32* merge_counter,
                     hipStream_t s);
 // z[perm[i]] = clip(u[i]); c[perm[i]] = z + lam[perm[i]]/rho  (local slice [off, off+nloc))
+// ---- distributed z-step (merge tree over ranks; pav.hip, CPU restatement oracle/zdist.py)
+struct ZdSeam {
+    int active, k, side, a0, b1;   // this rank's seam at the current level: id, 0 = left / 1 = right group, rank range
+    long long lo, hi, n;           // undecided index range [lo, hi) of the chunk (n positions)
+    double x, cnt;                 // pooled block: value and length
+};
+int launch_ehrm_fvals(int64_t n, const double* sa, const double* sb, double B, double rho, const double* ms,
+                      double* partials, double* out2, hipStream_t s);
+int launch_ehrm_pick(const double* fvals_total, int* branch, hipStream_t s);
+int launch_add_u32(int64_t n, u32* x, u32 add, hipStream_t s);
+int launch_zd_sample(const u64* keys, int64_t n, int ns, double* out, hipStream_t s);
+int launch_zd_split_bounds(const u64* keys, int64_t n, const double* split, int nsplit, long long* bounds, hipStream_t s);
+int launch_zd_bounds(const double* u, int64_t n, double* out3, hipStream_t s);
+int launch_zd_seam_setup(int rank, int world, int level, const double* bounds_all, int64_t n, ZdSeam* st, hipStream_t s);
+int launch_zd_update_propose(int loss, ZdSeam* st, const double* u, int K, int world, const double* cand_prev,
+                             const double* part_prev, double rho, double* cand_out, hipStream_t s);
+int launch_zd_eval(const ZdSeam* st, const double* u, Prefix pa, Prefix pb, Prefix pm, const int* branch, int K, int world,
+                   const double* cand_all, double* part, hipStream_t s);
+int launch_zd_pooled(const ZdSeam* st, Prefix pa, Prefix pb, Prefix pm, const int* branch, int nseams, double* sums, int* err,
+                     hipStream_t s);
+int launch_zd_fill(int loss, ZdSeam* st, const double* sums_total, double rho, double* u, int64_t n, hipStream_t s);
+int launch_zd_ids_to_keys(int64_t n, const u32* ids, u64* keys, u32* pos, hipStream_t s);
+int launch_zd_gather_back(int64_t n, const u64* keys_sorted, const u32* pos, const double* u, u32* out_ids, double* out_u,
+                          hipStream_t s);
+int launch_zd_owner_bounds(const u64* keys_sorted, int64_t n, int64_t nmax, int world, long long* bounds, hipStream_t s);
+int launch_zd_scatter(int64_t n, const u32* ids, const double* uu, const int* branch, double B, int has_B, double rho,
+                      const double* lam, double* z, double* c, int64_t off, int64_t nloc, hipStream_t s);
 int launch_scatter_z(int64_t n, const double* u, const u32* perm, const int* branch, double B, int has_B,
                      double rho, const double* lam, double* z, double* c, int64_t off, int64_t nloc,
                      hipStream_t s);

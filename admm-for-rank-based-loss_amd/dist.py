@@ -37,8 +37,8 @@ def shard_rows(n_total, world, rank):
 class _DevArray:
     """Zero-copy view of a librbl device buffer for torch (``__cuda_array_interface__``)."""
 
-    def __init__(self, ptr, count):
-        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
+    def __init__(self, ptr, count, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False),
                                          "version": 2, "strides": None}
 
 
@@ -106,6 +106,82 @@ class GpuEngine:
 
     def sync(self):
         torch.cuda.synchronize(self.device)
+
+    # ---------------------------------------------------------------- distributed z-step
+    # thin bindings of rbl_zd_* (include/rbl.h); the tensors are views of library buffers
+    def _zdv(self, which, typestr):
+        key = ("zd", which)
+        if key not in self._views:
+            ptr, cnt = self.s.buffer(which)
+            self._views[key] = torch.as_tensor(_DevArray(ptr, cnt, typestr), device=self.device)
+        return self._views[key]
+
+    def _small(self, lo, hi):
+        from . import _lib
+        return self._zdv(_lib.BUF_ZD_SMALL, "<f8")[lo:hi]
+
+    def zd_sort_local(self, nsamples):
+        self.s.zd_sort_local(nsamples)
+        return self._small(0, nsamples)
+
+    def zd_partition(self, splitters):
+        self._zd_world = splitters.numel() + 1
+        return self.s.zd_partition(splitters.data_ptr(), self._zd_world)
+
+    def zd_send_buffers(self):
+        from . import _lib
+        n = self.n_local
+        return self._zdv(_lib.BUF_ZD_SKEYS, "<i8")[:n], self._zdv(_lib.BUF_ZD_SIDS, "<i4")[:n]
+
+    def zd_recv_buffers(self, nrecv):
+        from . import _lib
+        self._zd_n = int(nrecv)
+        return self._zdv(_lib.BUF_ZD_RKEYS, "<i8")[:self._zd_n], self._zdv(_lib.BUF_ZD_RIDS, "<i4")[:self._zd_n]
+
+    def zd_prepare(self, nrecv, sigma_off):
+        self.s.zd_prepare(nrecv, sigma_off)
+        return self._small(260, 262)
+
+    def zd_pav(self, fvals_total):
+        self.s.zd_pav(fvals_total.data_ptr())
+
+    def zd_bounds(self):
+        self.s.zd_bounds()
+        return self._small(256, 259)
+
+    def zd_seam_setup(self, rank, world, level, bounds_all):
+        self._zd_world = world
+        self.s.zd_seam_setup(rank, world, level, bounds_all.data_ptr())
+
+    def zd_seam_propose(self, K, cand_all_prev, part_sum_prev):
+        self.s.zd_seam_propose(K, 0 if cand_all_prev is None else cand_all_prev.data_ptr(),
+                               0 if part_sum_prev is None else part_sum_prev.data_ptr())
+        return self._small(320, 320 + K)
+
+    def zd_seam_eval(self, K, cand_all):
+        self.s.zd_seam_eval(K, cand_all.data_ptr())
+        return self._small(512, 512 + 3 * K * self._zd_world)
+
+    def zd_seam_sums(self, K, cand_all_prev, part_sum_prev, nseams):
+        self.s.zd_seam_sums(K, cand_all_prev.data_ptr(), part_sum_prev.data_ptr(), nseams)
+        return self._small(12800, 12800 + 3 * nseams)
+
+    def zd_seam_fill(self, sums_total, nseams):
+        self.s.zd_seam_fill(sums_total.data_ptr())
+
+    def zd_return_partition(self, nmax, world):
+        return self.s.zd_return_partition(nmax, world)
+
+    def zd_back_send(self):
+        from . import _lib
+        return self._zdv(_lib.BUF_ZD_BIDS, "<i4")[:self._zd_n], self._zdv(_lib.BUF_ZD_BU, "<f8")[:self._zd_n]
+
+    def zd_back_recv(self, n):
+        from . import _lib
+        return self._zdv(_lib.BUF_ZD_ZIDS, "<i4")[:int(n)], self._zdv(_lib.BUF_ZD_ZU, "<f8")[:int(n)]
+
+    def zd_scatter(self, n):
+        self.s.zd_scatter(n)
 
 
 class ShardedADMM:

@@ -170,8 +170,53 @@ int  rbl_phase_finish(rbl_solver* h, rbl_stats* out);
 
 /* device buffers the host may pass to a collective */
 enum { RBL_BUF_M = 0, RBL_BUF_Q = 1, RBL_BUF_RED = 2, RBL_BUF_G = 3, RBL_BUF_V = 4, RBL_BUF_Z = 5,
-       RBL_BUF_LAM = 6, RBL_BUF_W = 7, RBL_BUF_COLSTATS = 8 };
+       RBL_BUF_LAM = 6, RBL_BUF_W = 7, RBL_BUF_COLSTATS = 8,
+       /* distributed z-step; the count returned is in ELEMENTS of the type given here */
+       RBL_BUF_ZD_SKEYS = 16,  /* int64 x n       sorted keys of the local rows (send)            */
+       RBL_BUF_ZD_SIDS = 17,   /* int32 x n       their global row ids (send)                      */
+       RBL_BUF_ZD_RKEYS = 18,  /* int64 x n_total keys received for the own range (capacity)       */
+       RBL_BUF_ZD_RIDS = 19,   /* int32 x n_total row ids received                                 */
+       RBL_BUF_ZD_SMALL = 20,  /* double x 16384  samples [0,256) | bounds [256,259) | EHRM sums
+                                  [260,262) | candidates [320,384) | partial sums [512,12800) |
+                                  seam sums [12800, ...)                                           */
+       RBL_BUF_ZD_BIDS = 21,   /* int32 x n_total row ids of the chunk, grouped by owner (send back) */
+       RBL_BUF_ZD_BU = 22,     /* double x n_total their block values (send back)                  */
+       RBL_BUF_ZD_ZIDS = 23,   /* int32 x n       row ids received back                            */
+       RBL_BUF_ZD_ZU = 24      /* double x n      block values received back                       */ };
 int  rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles);
+/* ---- distributed z-step for rank-weighted problems on several GPUs ---------------------------
+ * (no reference counterpart: the reference is single-process; what is distributed is
+ * algorithms.py:88-106.  Driver: admm-for-rank-based-loss_amd/dist.py:_z_distributed; CPU
+ * restatement of every call: oracle/zdist.py.)  After rbl_phase_m:
+ *   rbl_zd_sort_local        sort the local m (payload: global row id); ZD_SMALL[0,nsamples) = regular samples (NaN = none)
+ *   rbl_zd_partition         splitters (nparts-1 doubles, device) -> how many sorted rows go to each rank (host)
+ *   [all-to-all of ZD_SKEYS / ZD_SIDS into ZD_RKEYS / ZD_RIDS]
+ *   rbl_zd_prepare           sort the received chunk (n_recv rows, first sorted position sigma_off), prefix sums;
+ *                            ZD_SMALL[260,262) = this chunk's EHRM branch sums (to be summed over ranks)
+ *   rbl_zd_pav               exact PAV of the chunk (EHRM: branch from the summed values)
+ *   per level of the merge tree over ranks:
+ *     rbl_zd_bounds          ZD_SMALL[256,259) = (u_first, u_last, count)          [all-gather]
+ *     rbl_zd_seam_setup      this rank's seam / side / violation from all bounds
+ *     rounds x { rbl_zd_seam_propose -> ZD_SMALL[320,320+K)                         [all-gather]
+ *                rbl_zd_seam_eval    -> ZD_SMALL[512,512+3*world*K)                 [all-reduce] }
+ *     rbl_zd_seam_sums       ZD_SMALL[12800,12800+3*nseams)                        [all-reduce]
+ *     rbl_zd_seam_fill       pooled block value onto this rank's pooled positions
+ *   rbl_zd_return_partition  (row id, value) grouped by owner into ZD_BIDS / ZD_BU; counts per owner (host)
+ *   [all-to-all into ZD_ZIDS / ZD_ZU]
+ *   rbl_zd_scatter           z and c = z + lambda/rho of the local rows; then rbl_phase_q as usual. */
+int  rbl_zd_sort_local(rbl_solver* h, int nsamples);
+int  rbl_zd_partition(rbl_solver* h, const void* splitters_dev, int nparts, int64_t* send_counts);
+int  rbl_zd_prepare(rbl_solver* h, int64_t n_recv, int64_t sigma_off);
+int  rbl_zd_pav(rbl_solver* h, const void* fvals_total_dev);
+int  rbl_zd_bounds(rbl_solver* h);
+int  rbl_zd_seam_setup(rbl_solver* h, int rank, int world, int level, const void* bounds_all_dev);
+int  rbl_zd_seam_propose(rbl_solver* h, int K, const void* cand_all_prev_dev, const void* part_sum_prev_dev);
+int  rbl_zd_seam_eval(rbl_solver* h, int K, const void* cand_all_dev);
+int  rbl_zd_seam_sums(rbl_solver* h, int K, const void* cand_all_prev_dev, const void* part_sum_prev_dev, int nseams);
+int  rbl_zd_seam_fill(rbl_solver* h, const void* sums_total_dev);
+int  rbl_zd_return_partition(rbl_solver* h, int64_t nmax, int world, int64_t* counts);
+int  rbl_zd_scatter(rbl_solver* h, int64_t n_back);
+
 /* RBL_BUF_Q is the whole exchange buffer [q (ld) | D^T lambda seed (ld) | ||z||^2 | primal^2 |
  * sum loss]; RBL_BUF_RED is its 2-double tail.  After rbl_phase_q and after rbl_phase_dual this
  * tells which part awaits the sum over ranks: bit 0 = the first 2 ld + 1 doubles, bit 1 = the

@@ -34,7 +34,7 @@ def _run(rank, world, port, cfg, out):
         lo, cnt, _ = shard_rows(cfg["n"], world, rank)
         s = rbl.Solver(cnt, cfg["d"], cfg["wf"], cfg["loss"], reg=cfg["reg"], wstep=cfg["wstep"], B=cfg.get("B"),
                        args=cfg.get("args"), n_total=cfg["n"], row_offset=lo, tol=0.0, storage="f64")
-        drv = ShardedADMM(GpuEngine(s, 0))
+        drv = ShardedADMM(GpuEngine(s, 0), dist_z=cfg.get("dist_z", True))
         drv.setup_synthetic(seed=11)
         drv.setup_gram()
         hist = []
@@ -50,20 +50,42 @@ def _run(rank, world, port, cfg, out):
 
 @pytest.mark.parametrize("cfg", CFGS, ids=[c["wf"] for c in CFGS])
 def test_two_ranks_one_gpu_match_single_handle(cfg, tmp_path):
+    _check(cfg, 2, tmp_path)
+
+
+MORE = [
+    (4, dict(n=30001, d=33, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=6)),
+    (3, dict(n=25000, d=21, wf="aorr", args=[0.2, 0.8], loss="hinge", reg=1e-4, wstep=2, iters=6)),
+    (4, dict(n=20000, d=21, wf="ehrm", B=-5.0, loss="binary_cross_entropy", reg=0.01, wstep=2, iters=5)),
+    (2, dict(n=30001, d=33, wf="extremile", args=[2.0], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=5,
+             dist_z=False)),
+]
+
+
+@pytest.mark.parametrize("world,cfg", MORE, ids=["superq_w4", "aorr_hinge_w3", "ehrm_w4", "extremile_replicated_z"])
+def test_distributed_z_step_on_device(world, cfg, tmp_path):
+    """rank-weighted problems with the sorted order partitioned over 3 / 4 ranks on the device path
+    (rbl_zd_*: sample sort, chunk PAV, merge tree over ranks), and the replicated all-gather form."""
+    _check(cfg, world, tmp_path)
+
+
+def _check(cfg, world, tmp_path):
     import torch.multiprocessing as mp
     out1 = str(tmp_path / "w1_r%d.npz")
     out2 = str(tmp_path / "w2_r%d.npz")
-    port = 29600 + os.getpid() % 1000
+    port = 29600 + (os.getpid() + 13 * world) % 1000
     ctx = mp.get_context("spawn")
     p = ctx.Process(target=_run, args=(0, 1, port, cfg, out1))
     p.start(); p.join(300)
     assert p.exitcode == 0
-    mp.spawn(_run, args=(2, port, cfg, out2), nprocs=2, join=True)
+    mp.spawn(_run, args=(world, port, cfg, out2), nprocs=world, join=True)
     one = np.load(out1 % 0)
-    r0, r1 = np.load(out2 % 0), np.load(out2 % 1)
+    rs = [np.load(out2 % r) for r in range(world)]
+    r0, r1 = rs[0], rs[1]
     # replicated quantities agree between the ranks bit-for-bit
-    assert np.array_equal(r0["w"], r1["w"]) and np.array_equal(r0["hist"], r1["hist"])
-    z2 = np.concatenate([r0["z"], r1["z"]])
+    for r in rs[1:]:
+        assert np.array_equal(r0["w"], r["w"]) and np.array_equal(r0["hist"], r["hist"])
+    z2 = np.concatenate([r["z"] for r in rs])
     # sharding changes only the order of the fp64 partial sums (slabs per rank): ~1e-12
     assert np.max(np.abs(r0["w"] - one["w"])) <= 1e-9 * max(1.0, np.max(np.abs(one["w"])))
     assert np.max(np.abs(z2 - one["z"])) <= 1e-8 * max(1.0, np.max(np.abs(one["z"])))
