@@ -1405,7 +1405,9 @@ int rbl_zd_return_partition(rbl_solver* h, int64_t nmax, int world, int64_t* cou
     hipStream_t s = h->stream;
     int herr = 0;
     RBL_TRY(launch_zd_ids_to_keys(h->zd_n, h->sw.vals[0], h->sw.keys[0], h->sw.vals[0], s));
-    RBL_TRY(launch_radix_sort(h->sw, h->zd_n, true, s));
+    int id_bits = 1;
+    while (id_bits < 32 && (1LL << id_bits) < h->nt) ++id_bits;
+    RBL_TRY(launch_radix_sort(h->sw, h->zd_n, true, s, id_bits));   // row ids < n_total: 4 passes up to 2^32 rows
     RBL_TRY(launch_zd_owner_bounds(h->sw.keys[0], h->zd_n, nmax, world, h->zd_bounds_dev, s));
     RBL_TRY(launch_zd_gather_back(h->zd_n, h->sw.keys[0], h->sw.vals[0], h->pw.u, h->sw.vals[1], (double*)h->sw.keys[1], s));
     long long hb[65];

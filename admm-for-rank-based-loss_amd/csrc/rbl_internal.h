@@ -103,7 +103,8 @@ struct SortWorkspace {
 };
 size_t sort_spine_bytes();
 // sorts keys[0]/vals[0] ascending (stable); result ends in keys[0]/vals[0]
-int launch_radix_sort(SortWorkspace& ws, int64_t n, bool with_vals, hipStream_t s);
+// key_bits: number of low key bits that can differ (digits above are skipped)
+int launch_radix_sort(SortWorkspace& ws, int64_t n, bool with_vals, hipStream_t s, int key_bits = 64);
 
 // ---- pav.hip ----------------------------------------------------------------------------
 struct PavWorkspace {

@@ -218,15 +218,21 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64* __restrict
 
 size_t sort_spine_bytes() { return sizeof(u32) * RS_BINS * RS_MAX_BLOCKS; }
 
-int launch_radix_sort(SortWorkspace& ws, int64_t n, bool with_vals, hipStream_t s) {
+int launch_radix_sort(SortWorkspace& ws, int64_t n, bool with_vals, hipStream_t s, int key_bits) {
     if (n <= 1) return RBL_OK;
+    // keys known to fit key_bits bits need only that many digits; an even number of passes keeps
+    // the result in keys[0] / vals[0]
+    int npass = (key_bits + 7) / 8;
+    if (npass < 1) npass = 1;
+    npass = (npass + 1) & ~1;
+    if (npass > 8) npass = 8;
     if (n >= (1LL << 32)) {
         rbl_set_error("radix sort: n must be < 2^32");
         return RBL_ERR_INVALID;
     }
     RsPlan p = rs_plan(n);
     int cur = 0;
-    for (int pass = 0; pass < 8; ++pass) {
+    for (int pass = 0; pass < npass; ++pass) {
         const int shift = pass * 8;
         hipLaunchKernelGGL(k_rs_hist, dim3(p.nblocks), dim3(RS_THREADS), 0, s, ws.keys[cur], (long long)n, shift,
                            p.tiles_per_block, ws.spine, p.nblocks);
@@ -243,5 +249,5 @@ int launch_radix_sort(SortWorkspace& ws, int64_t n, bool with_vals, hipStream_t 
         cur ^= 1;
     }
     RBL_HIP(hipGetLastError());
-    return RBL_OK;  // 8 passes: the result is back in keys[0] / vals[0]
+    return RBL_OK;  // even number of passes: the result is back in keys[0] / vals[0]
 }

@@ -188,7 +188,7 @@ class ShardedADMM:
     """Drives one engine per rank through the phases with the collectives in between."""
 
     NS = 64      # regular samples per rank for the splitters
-    K = 15       # seam-search candidates per rank and round
+    K = 63       # seam-search candidates per rank and round (64-ary search: 5 rounds decide 16M positions)
 
     def __init__(self, engine, group=None, dist_z=True):
         self.e = engine
