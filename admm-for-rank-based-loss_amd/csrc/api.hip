@@ -958,7 +958,7 @@ int rbl_phase_dual(rbl_solver* h, int want_objective) {
                                  h->num_cu, h->stream, h->profile ? h->kev[5] : nullptr, want_objective));
         if (h->profile) h->kev_pending[2] = h->n > 0;
         h->fused_ran = true;
-        h->v_valid = true;
+        h->v_valid = want_objective != 0;   // without objective logging the pass does not store v (ensure_v recomputes it if a misprediction asks)
         if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[4], h->stream));
     } else if (h->fuse_v) {
         // v = D w and the lambda update in one pass (timed as the gemv of the iteration)

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
             if (lane < live && !(EXP & 1)) {
                 const long long row = (long long)q * SR + lane;
                 lam[row] = l_out;
-                v[row] = v_out;
+                if (v) v[row] = v_out;   // NULL: nobody reads v before the next pass (no objective logging)
                 if (!(EXP & 128)) z_new[row] = z_out;
             }
             zo = zoN;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(SEW_THREADS, 1) void k_sweep_erm_wide(
             if (tid < live) {
                 const long long row = (long long)q * SR + tid;
                 lam[row] = l_out;
-                v[row] = v_out;
+                if (v) v[row] = v_out;   // NULL: nobody reads v before the next pass (no objective logging)
                 z_new[row] = z_out;
             }
             zo = zoN;
@@ -604,6 +604,8 @@ int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld
                      hipEvent_t main_done, int want_obj) {
     const int grid = sweep_erm_blocks(num_cu);
     const int nrows = sweep_erm_is_wide(storage, ld) ? grid / 2 : grid;   // slab rows / partial triples produced
+    double* const v_for_loss = v;
+    if (!want_obj) v = nullptr;   // 8 of the 24 B/row of row-wise stores: only the loss sum reads v after the pass
     int rc;
     if (storage == RBL_STORE_F32) {
         rc = (loss == RBL_LOSS_BCE)
@@ -623,7 +625,7 @@ int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld
     RBL_HIP(hipGetLastError());
     // objective.py:11-24: the per-sample losses are summed from v in a pass of their own (8 B per
     // row) - exp/log1p inside the sweep cost registers on its critical path
-    if (want_obj) RBL_TRY(launch_loss_sum(loss, n, v, 1.0, partials, red + 1, s));
+    if (want_obj) RBL_TRY(launch_loss_sum(loss, n, v_for_loss, 1.0, partials, red + 1, s));
     return RBL_OK;
 }
 

@@ -192,6 +192,53 @@ def test_api_surface_and_errors(R):
         R.ADMMmethod(X, y, "erm", l2_reg=0.1, B=-5)
 
 
+def test_w_step_ahead_of_the_host_is_invisible(R):
+    """Single-sweep lasso iterations enqueue the NEXT w-step before the host has read the
+    current statistics (api.hip: rbl_phase_finish).  Whatever is called between two iterations
+    must see w_k and must not change the trajectory: the same solve (a) uninterrupted, (b) with
+    state reads / objective / accuracy calls between the iterations, (c) with
+    the look-ahead disabled, gives bit-identical iterates."""
+    import subprocess
+    import sys
+    import os
+    from oracle import problems
+    X, y = problems.make_problem(4000, 140, seed=9)
+
+    def run(poke):
+        s = R.ADMMmethod(X, y, "erm", "binary_cross_entropy", l1_reg=0.01, storage="f64", tol=0.0, max_iter=30)._s
+        ws, hist = [], []
+        for i in range(30):
+            st = s.step(i % 3 == 0)
+            hist.append((st.primal, st.dual, st.rho))
+            if poke:
+                w = s.get_state(want_z=False, want_lam=False)["w"]       # reads w_prev while w_{k+1} is in flight
+                ws.append(w.copy())
+                if i % 4 == 1:
+                    s.risk(w)                                            # cancels the look-ahead
+                if i % 4 == 2:
+                    s.accuracy(w)
+        return np.array(hist), s.get_state(), ws
+
+    h0, st0, _ = run(False)
+    h1, st1, ws = run(True)
+    assert np.array_equal(h0, h1)
+    for key in ("w", "z", "lam"):
+        assert np.array_equal(st0[key], st1[key]), key
+    # the w read after iteration k is what the dual residual of iteration k+1 is measured against
+    for i in range(1, 29):
+        assert abs(np.linalg.norm(ws[i] - ws[i - 1]) - h1[i, 1]) <= 1e-12 * max(1.0, h1[i, 1])
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); import admm_for_rank_based_loss_amd as R;"
+            "from oracle import problems; X, y = problems.make_problem(4000, 140, seed=9);"
+            "s = R.ADMMmethod(X, y, 'erm', 'binary_cross_entropy', l1_reg=0.01, storage='f64', tol=0.0, max_iter=30)._s;"
+            "h = [(lambda st: (st.primal, st.dual, st.rho))(s.step(i %% 3 == 0)) for i in range(30)];"
+            "print(json.dumps(dict(h=h, w=s.get_state()['w'].tolist())))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, RBL_NO_SPECULATE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert np.array_equal(np.array(r["h"]), h0) and np.array_equal(np.array(r["w"]), st0["w"])
+
+
 def test_objective_golden_g7(R):
     g = load_golden("g7_objective.npz")
     X, y, w = g["X"], g["y"], g["w"]
