@@ -342,7 +342,7 @@ int z_step_sorted(rbl_solver* h, const double* msrc, double rho) {
     RBL_TRY(launch_pav_tree(h->cfg.loss, nt, rho, h->pw.ms, h->sigma_a, h->sigma_b, h->pw.u, h->pa, h->pb, h->pm,
                             ehrm ? h->pw.branch : nullptr, h->pw.recs, h->pw.counters, s));
     RBL_TRY(launch_scatter_z(nt, h->pw.u, h->sw.vals[0], ehrm ? h->pw.branch : nullptr, h->cfg.B, ehrm ? 1 : 0, rho,
-                             h->lam, h->z, h->c, h->off, h->n, s));
+                             h->lam, h->z, nullptr, h->off, h->n, s));
     return RBL_OK;
 }
 
@@ -874,6 +874,10 @@ int rbl_phase_q(rbl_solver* h) {
     RBL_ENTER_ITER(h);
     if (!(h->fused_ok && h->z_ready)) {
         if (h->profile) RBL_HIP(hipEventRecord(h->kev[2], h->stream));
+        // rank-weighted problems: the z-step's scatter writes z alone (one random access per row); c = z +
+        // lambda/rho (algorithms.py:192) is a streaming pass here.  (Forming it inside the sweep was tried:
+        // the per-row division on the sweep's critical path costs 0.9 ms, the streaming pass 30 us.)
+        if (h->sorted_path) RBL_TRY(launch_make_c(h->n, h->z, h->lam, h->step_rho, h->c, h->stream));
         RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream,
                              h->profile ? h->kev[3] : nullptr));
         if (h->profile) h->kev_pending[1] = h->n > 0;
@@ -1432,7 +1436,7 @@ int rbl_zd_scatter(rbl_solver* h, int64_t n_back) {
     }
     const bool ehrm = h->cfg.weight_function == RBL_W_EHRM;
     RBL_TRY(launch_zd_scatter(n_back, h->zd_zids, h->m, ehrm ? h->pw.branch : nullptr, h->cfg.B, ehrm ? 1 : 0, h->step_rho,
-                              h->lam, h->z, h->c, h->off, h->n, h->stream));
+                              h->lam, h->z, nullptr, h->off, h->n, h->stream));
     if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[1], h->stream));
     return RBL_OK;
 }

@@ -831,6 +831,20 @@ __global__ void k_add_u32(long long n, u32* __restrict__ x, u32 add) {
         x[i] += add;
 }
 }  // namespace
+namespace {
+__global__ void k_make_c(long long n, const double* __restrict__ z, const double* __restrict__ lam, double rho,
+                         double* __restrict__ c) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        c[i] = z[i] + lam[i] / rho;   // algorithms.py:192
+}
+}  // namespace
+int launch_make_c(int64_t n, const double* z, const double* lam, double rho, double* c, hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    hipLaunchKernelGGL(k_make_c, dim3(pv_grid(n, 256, 4096)), dim3(256), 0, s, (long long)n, z, lam, rho, c);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
 int launch_add_u32(int64_t n, u32* x, u32 add, hipStream_t s) {
     if (n <= 0) return RBL_OK;
     hipLaunchKernelGGL(k_add_u32, dim3(pv_grid(n)), dim3(256), 0, s, (long long)n, x, add);

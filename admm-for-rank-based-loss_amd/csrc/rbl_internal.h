@@ -148,6 +148,7 @@ int launch_ehrm_fvals(int64_t n, const double* sa, const double* sb, double B, d
                       double* partials, double* out2, hipStream_t s);
 int launch_ehrm_pick(const double* fvals_total, int* branch, hipStream_t s);
 int launch_add_u32(int64_t n, u32* x, u32 add, hipStream_t s);
+int launch_make_c(int64_t n, const double* z, const double* lam, double rho, double* c, hipStream_t s);
 int launch_zd_sample(const u64* keys, int64_t n, int ns, double* out, hipStream_t s);
 int launch_zd_split_bounds(const u64* keys, int64_t n, const double* split, int nsplit, long long* bounds, hipStream_t s);
 int launch_zd_bounds(const double* u, int64_t n, double* out3, hipStream_t s);
@@ -178,7 +179,8 @@ struct WstepWorkspace {
     double* p;      // d (CG)
     double* scal;   // small device scalars: [0]=t, [1]=rr, ...
     int* flags;     // [0]=done, [1]=iters
-    int* pin;       // host-pinned, device-visible: [0..3] = status block of the active-set lasso kernel
+    int* pin;       // host-pinned, device-visible: [0..3] = status block of the active-set lasso kernel, [4..5] = CG (done, iterations)
+    int last_iters; // CG iterations of the previous w-step (sizes the next batch)
 };
 int launch_power_iteration(const double* G, int64_t d, double* tmp1, double* tmp2, double* scal, int iters,
                            double* lambda_host, hipStream_t s);

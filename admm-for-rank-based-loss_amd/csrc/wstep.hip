@@ -151,8 +151,17 @@ __global__ __launch_bounds__(UPD_THREADS) void k_cg_init(long long ld, const dou
 __global__ __launch_bounds__(UPD_THREADS) void k_cg_update(long long ld, const double* __restrict__ Ap,
                                                             double* __restrict__ w, double* __restrict__ r,
                                                             double* __restrict__ p, double* __restrict__ scal,
-                                                            int* __restrict__ flags) {
-    if (flags[0]) return;
+                                                            int* __restrict__ flags, int* __restrict__ publish) {
+    // publish != NULL on the last update of a batch: (done, iterations) go to pinned host memory
+    // the host spins on, word 0 last
+    if (flags[0]) {
+        if (publish && threadIdx.x == 0) {
+            publish[1] = flags[1];
+            __threadfence_system();
+            publish[0] = 1;
+        }
+        return;
+    }
     __shared__ double smem[UPD_THREADS / 64];
     double pk[UPD_PER], rk[UPD_PER];
     double acc[1] = {0.0};
@@ -189,8 +198,15 @@ __global__ __launch_bounds__(UPD_THREADS) void k_cg_update(long long ld, const d
     __syncthreads();
     if (threadIdx.x == 0) {
         scal[1] = acc2[0];
-        flags[1] += 1;
-        if (acc2[0] <= scal[2] || alpha == 0.0) flags[0] = 1;
+        const int it = flags[1] + 1;
+        const int done = (acc2[0] <= scal[2] || alpha == 0.0) ? 1 : 0;
+        flags[1] = it;
+        if (done) flags[0] = 1;
+        if (publish) {
+            publish[1] = it;
+            __threadfence_system();
+            publish[0] = done;
+        }
     }
 }
 
@@ -341,28 +357,37 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
         return RBL_ERR_INVALID;
     }
     if (wstep == RBL_WSTEP_L2) {
-        // (rho G + reg I) w = rho q
+        // (rho G + reg I) w = rho q.  The warm-started CG needs about as many iterations as last
+        // time: one batch of that many (+2) is enqueued, its last update publishes (done,
+        // iterations) to pinned memory and the host spins on that word - one host round trip per
+        // w-step and no device-to-host copy; updates after convergence are no-ops (device flag).
         const unsigned sg = symv_grid(ld);
-        int hflags[2] = {0, 0};
-        constexpr int BATCH = 8;
         hipLaunchKernelGGL(k_symv, dim3(sg), dim3(256), 0, s, G, (long long)ld, w, ws.Gy, rho, reg, (const int*)nullptr);
         hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(UPD_THREADS), 0, s, (long long)ld, ws.Gy, q, rho, ws.r, ws.p, tol,
                            ws.scal, ws.flags);
-        int done_iters = 0;
+        int batch = ws.last_iters > 0 ? ws.last_iters + 2 : 16;
+        if (batch < 4) batch = 4;
+        if (batch > 64) batch = 64;
+        int done_iters = 0, done = 0, iters = 0;
         while (done_iters < max_inner) {
-            for (int b = 0; b < BATCH; ++b) {
+            ws.pin[4] = -1;
+            for (int b = 0; b < batch; ++b) {
                 hipLaunchKernelGGL(k_symv, dim3(sg), dim3(256), 0, s, G, (long long)ld, ws.p, ws.Gy, rho, reg, ws.flags);
                 hipLaunchKernelGGL(k_cg_update, dim3(1), dim3(UPD_THREADS), 0, s, (long long)ld, ws.Gy, w, ws.r, ws.p,
-                                   ws.scal, ws.flags);
+                                   ws.scal, ws.flags, b == batch - 1 ? ws.pin + 4 : (int*)nullptr);
             }
-            done_iters += BATCH;
-            RBL_HIP(hipMemcpyAsync(hflags, ws.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-            RBL_HIP(hipStreamSynchronize(s));
-            if (hflags[0]) break;
+            RBL_HIP(hipGetLastError());
+            done_iters += batch;
+            rbl_spin_wait(ws.pin + 4, -1, s);
+            const volatile int* st = ws.pin + 4;
+            done = st[0];
+            iters = st[1];
+            if (done != 0) break;   // 1 = converged (-1 after the spin's stream wait: launch failure, stop too)
+            batch = 8;
         }
-        RBL_HIP(hipGetLastError());
-        if (iters_host) *iters_host = hflags[1];
-        return RBL_OK;
+        if (done == 1) ws.last_iters = iters;
+        if (iters_host) *iters_host = iters;
+        return done == -1 ? RBL_ERR_HIP : RBL_OK;
     }
     if (wstep == RBL_WSTEP_L1) {
         // exact active-set solve first (lasso_fs.hip); FISTA only when the support does not fit
