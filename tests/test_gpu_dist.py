@@ -90,3 +90,15 @@ def _check(cfg, world, tmp_path):
     assert np.max(np.abs(r0["w"] - one["w"])) <= 1e-9 * max(1.0, np.max(np.abs(one["w"])))
     assert np.max(np.abs(z2 - one["z"])) <= 1e-8 * max(1.0, np.max(np.abs(one["z"])))
     assert np.allclose(r0["hist"], one["hist"], rtol=1e-8, atol=1e-12)
+
+
+def test_rccl_accepts_the_library_views_one_rank():
+    """The box has one GPU and RCCL refuses two ranks per device, so the nccl backend can only be
+    exercised with world_size 1: a sharded step, every collective of the driver on the library's
+    zero-copy views (float64 / int64 / int32) and the whole distributed z-step protocol run through
+    RCCL and give the single-handle z bit for bit (tools/rccl_view_smoke.py)."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_view_smoke.py")], capture_output=True, text=True,
+                         timeout=600, env=dict(os.environ, MASTER_PORT=str(29700 + os.getpid() % 200)))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert out.stdout.strip().splitlines()[-1] == "OK"
