@@ -62,7 +62,14 @@ MORE = [
 ]
 
 
-@pytest.mark.parametrize("world,cfg", MORE, ids=["superq_w4", "aorr_hinge_w3", "ehrm_w4", "extremile_replicated_z"])
+MORE += [
+    (4, dict(n=5, d=3, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=4)),   # rank 3 owns no row
+    (3, dict(n=4099, d=5, wf="esrm", args=[1.0], loss="hinge", reg=0.01, wstep=1, iters=6)),
+]
+
+
+@pytest.mark.parametrize("world,cfg", MORE, ids=["superq_w4", "aorr_hinge_w3", "ehrm_w4", "extremile_replicated_z",
+                                                  "tiny_with_an_empty_rank", "esrm_hinge_l1_w3"])
 def test_distributed_z_step_on_device(world, cfg, tmp_path):
     """rank-weighted problems with the sorted order partitioned over 3 / 4 ranks on the device path
     (rbl_zd_*: sample sort, chunk PAV, merge tree over ranks), and the replicated all-gather form."""

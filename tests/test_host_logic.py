@@ -129,7 +129,9 @@ def test_sharded_driver_world2_gloo_matches_single_process(cfg, tmp_path):
     (4, dict(n=300, d=6, seed=6, wf="ehrm", B=-5, loss="binary_cross_entropy", reg=0.01, l1=False, iters=8)),
     (2, dict(n=501, d=9, seed=4, wf="extremile", args=[2.0], loss="binary_cross_entropy", reg=0.01, l1=False, iters=8,
              dist_z=False)),
-], ids=["superq_world3", "aorr_world4", "ehrm_world4", "extremile_replicated_z"])
+    (4, dict(n=5, d=3, seed=8, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, l1=False, iters=5)),
+    (3, dict(n=64, d=4, seed=9, wf="esrm", args=[1.0], loss="hinge", reg=0.01, l1=True, iters=6)),
+], ids=["superq_world3", "aorr_world4", "ehrm_world4", "extremile_replicated_z", "tiny_with_an_empty_rank", "esrm_hinge_l1_world3"])
 def test_distributed_z_step_more_ranks(world, cfg, tmp_path):
     """rank-weighted problems with the sorted order partitioned over 3 / 4 ranks (sample sort,
     local PAV, merge tree over ranks: dist.py:_z_distributed on the NumPy engine), and the
