@@ -211,8 +211,8 @@ int alloc_prefix(double** locx, double** chunk, double** cph, double** cpl, int6
     return RBL_OK;
 }
 
-// the lasso kernel's status block lives in pinned host memory the device writes directly, and an
-// event marks its completion: the host reads the status without a copy or a stream-wide wait
+// the status blocks of the lasso kernel and of the CG batches live in pinned host memory the device
+// writes directly (status word last): the host spins on the word - no copy, no stream-wide wait
 int alloc_wstep_pin(WstepWorkspace& ww) {
     void* pin = nullptr;
     RBL_HIP(hipHostMalloc(&pin, 64, hipHostMallocCoherent));

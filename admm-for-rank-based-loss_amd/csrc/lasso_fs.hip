@@ -345,7 +345,6 @@ __global__ __launch_bounds__(FS_THREADS) void k_lasso_fs(const double* __restric
 
 }  // namespace
 
-size_t lasso_fs_lds_bytes() { return sizeof(FsShared); }
 
 int launch_lasso_fs(const double* G, int64_t ld, int64_t d, const double* q, double* w, double kappa, int* out_dev,
                     hipStream_t s, const double* rho_dev, double reg, double* w_prev_out) {

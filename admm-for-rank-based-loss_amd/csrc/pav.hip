@@ -433,24 +433,6 @@ __global__ void k_unflip(long long n, const u64* __restrict__ keys, double* __re
         ms[i] = rbl::unflip_key(keys[i]);
 }
 
-template <int LOSS>
-__global__ __launch_bounds__(PV_THREADS) void k_pav_init(long long n, const double* __restrict__ sigma, double rho,
-                                                          const double* __restrict__ ms, double* __restrict__ u) {
-    for (long long i = (long long)blockIdx.x * PV_THREADS + threadIdx.x; i < n;
-         i += (long long)gridDim.x * PV_THREADS)
-        u[i] = rbl::prox<LOSS>(sigma[i], rho, ms[i]);
-}
-
-__global__ __launch_bounds__(PV_THREADS) void k_pav_init_ehrm(long long n, const double* __restrict__ sa,
-                                                               const double* __restrict__ sb, double rho,
-                                                               const double* __restrict__ ms, double* __restrict__ u,
-                                                               const int* __restrict__ branch) {
-    const double* sg = (*branch) ? sb : sa;
-    for (long long i = (long long)blockIdx.x * PV_THREADS + threadIdx.x; i < n;
-         i += (long long)gridDim.x * PV_THREADS)
-        u[i] = rbl::prox_bce(sg[i], rho, ms[i]);
-}
-
 // EHRM singleton-stage scalar test (src/util/PAV_cpt.py:205-226): opt1 = min(prox_a, B),
 // opt2 = max(prox_b, B); fval_k = sum sigma_k*log(1+exp(opt_k)) + rho/2 ||opt_k - m||^2
 __global__ __launch_bounds__(PV_THREADS) void k_ehrm_fvals(long long n, const double* __restrict__ sa,
@@ -790,17 +772,6 @@ int launch_unflip_keys(int64_t n, const u64* keys, double* ms, hipStream_t s) {
     return RBL_OK;
 }
 
-int launch_pav_init(int loss, int64_t n, const double* sigma, double rho, const double* ms, double* u,
-                    hipStream_t s) {
-    if (n <= 0) return RBL_OK;
-    if (loss == RBL_LOSS_BCE)
-        hipLaunchKernelGGL(k_pav_init<0>, dim3(pv_grid(n)), dim3(PV_THREADS), 0, s, (long long)n, sigma, rho, ms, u);
-    else
-        hipLaunchKernelGGL(k_pav_init<1>, dim3(pv_grid(n)), dim3(PV_THREADS), 0, s, (long long)n, sigma, rho, ms, u);
-    RBL_HIP(hipGetLastError());
-    return RBL_OK;
-}
-
 int launch_ehrm_branch(int64_t n, const double* sa, const double* sb, double B, double rho, const double* ms,
                        double* partials, int* branch, int forced, hipStream_t s) {
     const int nb = reduce_blocks();
@@ -848,15 +819,6 @@ int launch_make_c(int64_t n, const double* z, const double* lam, double rho, dou
 int launch_add_u32(int64_t n, u32* x, u32 add, hipStream_t s) {
     if (n <= 0) return RBL_OK;
     hipLaunchKernelGGL(k_add_u32, dim3(pv_grid(n)), dim3(256), 0, s, (long long)n, x, add);
-    RBL_HIP(hipGetLastError());
-    return RBL_OK;
-}
-
-int launch_pav_init_ehrm(int64_t n, const double* sa, const double* sb, double rho, const double* ms, double* u,
-                         const int* branch, hipStream_t s) {
-    if (n <= 0) return RBL_OK;
-    hipLaunchKernelGGL(k_pav_init_ehrm, dim3(pv_grid(n)), dim3(PV_THREADS), 0, s, (long long)n, sa, sb, rho, ms, u,
-                       branch);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

@@ -124,14 +124,9 @@ int64_t pav_num_recs(int64_t n);
 int launch_prefix(const double* x, int64_t n, double* locx, double* chunk_tot, double* cph, double* cpl,
                   hipStream_t s);
 int launch_unflip_keys(int64_t n, const u64* keys, double* ms, hipStream_t s);
-// u = prox(sigma_i, ms_i) per sorted position
-int launch_pav_init(int loss, int64_t n, const double* sigma, double rho, const double* ms, double* u,
-                    hipStream_t s);
-// EHRM: scalar branch test (PAV_cpt.py:205-226) -> *branch, then u = prox(sigma_branch, ms)
+// EHRM: scalar branch test (PAV_cpt.py:205-226) -> *branch
 int launch_ehrm_branch(int64_t n, const double* sa, const double* sb, double B, double rho, const double* ms,
                        double* partials, int* branch, int forced, hipStream_t s);
-int launch_pav_init_ehrm(int64_t n, const double* sa, const double* sb, double rho, const double* ms,
-                         double* u, const int* branch, hipStream_t s);
 // element prox (level 0) + merge tree -> u.  sigma = sa, or sb when *branch != 0 (EHRM); the
 // matching prefix sums are pa / pb.
 int launch_pav_tree(int loss, int64_t n, double rho, const double* ms, const double* sa, const double* sb, double* u,
@@ -200,7 +195,6 @@ int launch_w_stats(int64_t d, const double* w, const double* w_prev, double* out
 // rho_dev != NULL: kappa = reg / (2 rho_dev[0]) is formed on the device; w_prev_out != NULL: the warm start is saved there
 int launch_lasso_fs(const double* G, int64_t ld, int64_t d, const double* q, double* w, double kappa, int* out_dev,
                     hipStream_t s, const double* rho_dev = nullptr, double reg = 0.0, double* w_prev_out = nullptr);
-int launch_diffnorm2(int64_t d, const double* a, const double* b, double* out, hipStream_t s);
 int launch_reg_terms(int64_t d, const double* w, double* out2 /* [sum w^2, sum |w|] */, hipStream_t s);
 int launch_soft_threshold(int64_t d, double* w, double t, hipStream_t s);
 

@@ -232,18 +232,6 @@ __global__ void k_power_init(long long ld, long long d, double* __restrict__ x) 
     }
 }
 
-__global__ __launch_bounds__(UPD_THREADS) void k_diffnorm2(long long d, const double* __restrict__ a,
-                                                            const double* __restrict__ b, double* __restrict__ out) {
-    __shared__ double smem[UPD_THREADS / 64];
-    double acc[1] = {0.0};
-    for (long long j = threadIdx.x; j < d; j += UPD_THREADS) {
-        const double t = a[j] - b[j];
-        acc[0] += t * t;
-    }
-    rbl::block_sum<1, UPD_THREADS>(acc, smem);
-    if (threadIdx.x == 0) out[0] = acc[0];
-}
-
 __global__ __launch_bounds__(UPD_THREADS) void k_reg_terms(long long d, const double* __restrict__ w,
                                                             double* __restrict__ out) {
     __shared__ double smem[2 * UPD_THREADS / 64];
@@ -420,12 +408,6 @@ int finish_wstep_l1(const double* G, int64_t ld, const double* q, double rho, do
 
 int launch_symv(const double* G, int64_t ld, const double* x, double* y, hipStream_t s) {
     hipLaunchKernelGGL(k_symv, dim3(symv_grid(ld)), dim3(256), 0, s, G, (long long)ld, x, y, 1.0, 0.0, (const int*)nullptr);
-    RBL_HIP(hipGetLastError());
-    return RBL_OK;
-}
-
-int launch_diffnorm2(int64_t d, const double* a, const double* b, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_diffnorm2, dim3(1), dim3(UPD_THREADS), 0, s, (long long)d, a, b, out);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }
