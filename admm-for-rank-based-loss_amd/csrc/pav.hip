@@ -178,6 +178,54 @@ __device__ inline long long lower_bound_ge(const Acc& ac, long long lo, long lon
     return lo;
 }
 
+// Wave-cooperative accessor for the upper levels: a whole wave runs seam_merge() on ONE seam with
+// identical arguments in all 64 lanes; the inner binary searches become 64-ary (each step samples
+// 64 positions with one load per lane and a ballot), so a search over 3M positions takes 4
+// dependent loads instead of 22.  Reads of single values / prefix sums are wave-uniform loads.
+struct WaveAcc {
+    const double* u;
+    Prefix pa, pm;
+    __device__ inline double val(long long i) const { return u[i]; }
+    __device__ inline double sum_a(long long s, long long e1) const { return range_sum(pa, s, e1); }
+    __device__ inline double sum_m(long long s, long long e1) const { return range_sum(pm, s, e1); }
+};
+template <bool STRICT>   // STRICT: first i with u[i] > t;  else first i with u[i] >= t
+__device__ inline long long wave_first(const double* __restrict__ u, long long lo, long long hi, double t) {
+    const int lane = threadIdx.x & 63;
+    // invariant: the answer is the first position in [lo, hi) that satisfies the predicate, or hi
+    while (hi - lo > 64) {
+        const long long step = (hi - lo + 63) >> 6;
+        const long long p = lo + (long long)lane * step + (step - 1);   // last position of chunk `lane`
+        bool pred = true;                                               // chunks past hi count as satisfied
+        if (p < hi) {
+            const double x = u[p];
+            pred = STRICT ? (x > t) : (x >= t);
+        }
+        const unsigned long long mask = __ballot(pred);
+        if (mask == 0ull) return hi;
+        const int j = __ffsll((long long)mask) - 1;   // first chunk whose last position satisfies it
+        const long long nlo = lo + (long long)j * step;
+        const long long pj = nlo + step - 1;
+        lo = nlo;
+        if (pj < hi) hi = pj;   // u[pj] satisfies the predicate: it is the answer unless an earlier one does
+    }
+    const long long p = lo + lane;
+    bool pred = true;
+    if (p < hi) {
+        const double x = u[p];
+        pred = STRICT ? (x > t) : (x >= t);
+    }
+    const unsigned long long mask = __ballot(pred);
+    const long long r = lo + (__ffsll((long long)mask) - 1);
+    return r < hi ? r : hi;
+}
+__device__ inline long long upper_bound_gt(const WaveAcc& ac, long long lo, long long hi, double t) {
+    return lo < hi ? wave_first<true>(ac.u, lo, hi, t) : lo;
+}
+__device__ inline long long lower_bound_ge(const WaveAcc& ac, long long lo, long long hi, double t) {
+    return lo < hi ? wave_first<false>(ac.u, lo, hi, t) : lo;
+}
+
 // Joins the solved segments [L0, seam) and [seam, R1) (seam violates: u[seam-1] > u[seam]).
 // Returns the pooled range [s*, e*] and its value.
 template <int LOSS, typename Acc>
@@ -416,6 +464,34 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_seam(double* __restrict__ u,
     recs[k].s = s_star;
     recs[k].e = e_star;
     recs[k].x = x;
+}
+
+// One WAVE per seam (the levels where seams are few and long): see WaveAcc.
+template <int LOSS>
+__global__ __launch_bounds__(PV_THREADS) void k_pav_seam_wave(double* __restrict__ u, long long n, long long half,
+                                                               Prefix pa_, Prefix pb_, Prefix pm, const int* branch,
+                                                               double rho, SeamRec* __restrict__ recs,
+                                                               long long nseams, u32* __restrict__ merge_counter) {
+    const long long k = ((long long)blockIdx.x * PV_THREADS + threadIdx.x) >> 6;   // wave-uniform
+    const int lane = threadIdx.x & 63;
+    if (k >= nseams) return;
+    const long long seam = (2 * k + 1) * half;
+    if (seam >= n || u[seam - 1] <= u[seam]) {  // pav.py:105 - only a strict decrease is a violation
+        if (lane == 0) recs[k].s = -1;
+        return;
+    }
+    const WaveAcc ac{u, (branch && *branch) ? pb_ : pa_, pm};
+    long long R1 = seam + half;
+    if (R1 > n) R1 = n;
+    long long s_star, e_star;
+    double x;
+    seam_merge<LOSS>(ac, seam - half, seam, R1, rho, s_star, e_star, x);
+    if (lane == 0) {
+        atomicAdd(merge_counter, 1u);
+        recs[k].s = s_star;
+        recs[k].e = e_star;
+        recs[k].x = x;
+    }
 }
 
 __global__ void k_pav_fill(double* __restrict__ u, long long n, int level_shift, const SeamRec* __restrict__ recs) {
@@ -836,17 +912,31 @@ int launch_pav_tree(int loss, int64_t n, double rho, const double* ms, const dou
     else
         hipLaunchKernelGGL(k_pav_bottom<1>, dim3(tiles), dim3(PV_THREADS), 0, s, ms, sa, sb, branch, rho, (long long)n, u,
                            merge_counter);
-    // upper levels: one thread per seam, pooled ranges written by a fill pass
+    // upper levels: one WAVE per seam (64-ary inner searches), pooled ranges written by a fill pass
+    static const bool thread_seams = [] {
+        const char* e = getenv("RBL_PAV_THREAD_SEAMS");   // the one-thread-per-seam kernel, for comparison
+        return e && e[0] == '1';
+    }();
     int level = PB_TILE_LOG + 1;
     for (long long half = PB_TILE; half < n; half <<= 1, ++level) {
         const long long nseams = (n + 2 * half - 1) / (2 * half);
-        const unsigned grid = pv_grid(nseams, PV_THREADS, 1LL << 30);
-        if (loss == RBL_LOSS_BCE)
-            hipLaunchKernelGGL(k_pav_seam<0>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, half, pa, pb, pm,
-                               branch, rho, recs, nseams, merge_counter);
-        else
-            hipLaunchKernelGGL(k_pav_seam<1>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, half, pa, pb, pm,
-                               branch, rho, recs, nseams, merge_counter);
+        if (thread_seams) {
+            const unsigned grid = pv_grid(nseams, PV_THREADS, 1LL << 30);
+            if (loss == RBL_LOSS_BCE)
+                hipLaunchKernelGGL(k_pav_seam<0>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, half, pa, pb, pm,
+                                   branch, rho, recs, nseams, merge_counter);
+            else
+                hipLaunchKernelGGL(k_pav_seam<1>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, half, pa, pb, pm,
+                                   branch, rho, recs, nseams, merge_counter);
+        } else {
+            const unsigned grid = pv_grid(nseams * 64, PV_THREADS, 1LL << 30);
+            if (loss == RBL_LOSS_BCE)
+                hipLaunchKernelGGL(k_pav_seam_wave<0>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, half, pa, pb,
+                                   pm, branch, rho, recs, nseams, merge_counter);
+            else
+                hipLaunchKernelGGL(k_pav_seam_wave<1>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, half, pa, pb,
+                                   pm, branch, rho, recs, nseams, merge_counter);
+        }
         hipLaunchKernelGGL(k_pav_fill, dim3(pv_grid(n)), dim3(256), 0, s, u, (long long)n, level, recs);
     }
     RBL_HIP(hipGetLastError());

@@ -22,6 +22,8 @@ CFGS = [
 
 def _run(rank, world, port, cfg, out):
     sys.path.insert(0, ROOT)
+    if world > 1:
+        os.environ.update(cfg.get("env", {}))     # only the sharded run: the single-handle run stays the plain path
     import torch
     import torch.distributed as dist
     import admm_for_rank_based_loss_amd as rbl
@@ -63,13 +65,17 @@ MORE = [
 
 
 MORE += [
+    # every 3rd rho prediction corrupted on both ranks: the verification + two-sweep redo (and its two
+    # partial all-reduces) inside the sharded driver
+    (2, dict(n=40000, d=48, wf="erm", loss="binary_cross_entropy", reg=0.01, wstep=1, iters=9,
+             env={"RBL_DEBUG_MISPREDICT_EVERY": "3"})),
     (4, dict(n=5, d=3, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=4)),   # rank 3 owns no row
     (3, dict(n=4099, d=5, wf="esrm", args=[1.0], loss="hinge", reg=0.01, wstep=1, iters=6)),
 ]
 
 
 @pytest.mark.parametrize("world,cfg", MORE, ids=["superq_w4", "aorr_hinge_w3", "ehrm_w4", "extremile_replicated_z",
-                                                  "tiny_with_an_empty_rank", "esrm_hinge_l1_w3"])
+                                                  "erm_mispredictions_w2", "tiny_with_an_empty_rank", "esrm_hinge_l1_w3"])
 def test_distributed_z_step_on_device(world, cfg, tmp_path):
     """rank-weighted problems with the sorted order partitioned over 3 / 4 ranks on the device path
     (rbl_zd_*: sample sort, chunk PAV, merge tree over ranks), and the replicated all-gather form."""
