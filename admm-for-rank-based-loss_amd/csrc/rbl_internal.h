@@ -176,6 +176,7 @@ struct WstepWorkspace {
     int* flags;     // [0]=done, [1]=iters
     int* pin;       // host-pinned, device-visible: [0..3] = status block of the active-set lasso kernel, [4..5] = CG (done, iterations)
     int last_iters; // CG iterations of the previous w-step (sizes the next batch)
+    int last_fista; // the same for FISTA; pin[6..7] = its (done, iterations)
 };
 int launch_power_iteration(const double* G, int64_t d, double* tmp1, double* tmp2, double* scal, int iters,
                            double* lambda_host, hipStream_t s);

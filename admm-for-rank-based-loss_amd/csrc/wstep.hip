@@ -64,8 +64,17 @@ __device__ inline double huber_prox(double b, double Ls, double reg, double t) {
 __global__ __launch_bounds__(UPD_THREADS) void k_fista_update(long long ld, const double* __restrict__ Gy,
                                                                const double* __restrict__ q, double* __restrict__ w,
                                                                double* __restrict__ yk, FistaParams P,
-                                                               double* __restrict__ scal, int* __restrict__ flags) {
-    if (flags[0]) return;
+                                                               double* __restrict__ scal, int* __restrict__ flags,
+                                                               int* __restrict__ publish) {
+    // publish != NULL on the last update of a batch: (done, iterations) to pinned host memory, word 0 last
+    if (flags[0]) {
+        if (publish && threadIdx.x == 0) {
+            publish[1] = flags[1];
+            __threadfence_system();
+            publish[0] = 1;
+        }
+        return;
+    }
     __shared__ double smem[3 * UPD_THREADS / 64];
     double wn[UPD_PER], dw[UPD_PER];
     double acc[1] = {0.0};  // restart test: sum (y - x)(x - w)
@@ -119,8 +128,15 @@ __global__ __launch_bounds__(UPD_THREADS) void k_fista_update(long long ld, cons
     __syncthreads();
     if (threadIdx.x == 0) {
         scal[0] = tn;
-        flags[1] += 1;
-        if (mx_dw <= P.tol * fmax(1.0, mx_w)) flags[0] = 1;
+        const int it = flags[1] + 1;
+        const int done = (mx_dw <= P.tol * fmax(1.0, mx_w)) ? 1 : 0;
+        flags[1] = it;
+        if (done) flags[0] = 1;
+        if (publish) {
+            publish[1] = it;
+            __threadfence_system();
+            publish[0] = done;
+        }
     }
 }
 
@@ -304,7 +320,6 @@ int run_fista(int mode, const double* G, int64_t ld, const double* q, double rho
               double tol, int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s) {
     constexpr int BATCH = 8;
     const unsigned sg = symv_grid(ld);
-    int hflags[2] = {0, 0};
     FistaParams P;
     P.mode = mode;
     P.L = L;
@@ -317,21 +332,31 @@ int run_fista(int mode, const double* G, int64_t ld, const double* q, double rho
     RBL_HIP(hipMemcpyAsync(ws.scal, &one, sizeof(double), hipMemcpyHostToDevice, s));
     RBL_HIP(hipMemsetAsync(ws.flags, 0, 2 * sizeof(int), s));
     RBL_HIP(hipMemcpyAsync(ws.yk, w, sizeof(double) * ld, hipMemcpyDeviceToDevice, s));
-    int done_iters = 0;
+    // same batching as the CG: about as many iterations as last time (+25 %) per host round trip,
+    // (done, iterations) published to pinned memory by the batch's last update
+    int batch = ws.last_fista > 0 ? ws.last_fista + ws.last_fista / 4 + 2 : 4 * BATCH;
+    if (batch < BATCH) batch = BATCH;
+    if (batch > 512) batch = 512;
+    int done_iters = 0, done = 0, iters = 0;
     while (done_iters < max_inner) {
-        for (int b = 0; b < BATCH; ++b) {
+        ws.pin[6] = -1;
+        for (int b = 0; b < batch; ++b) {
             hipLaunchKernelGGL(k_symv, dim3(sg), dim3(256), 0, s, G, (long long)ld, ws.yk, ws.Gy, 1.0, 0.0, ws.flags);
             hipLaunchKernelGGL(k_fista_update, dim3(1), dim3(UPD_THREADS), 0, s, (long long)ld, ws.Gy, q, w, ws.yk, P,
-                               ws.scal, ws.flags);
+                               ws.scal, ws.flags, b == batch - 1 ? ws.pin + 6 : (int*)nullptr);
         }
-        done_iters += BATCH;
-        RBL_HIP(hipMemcpyAsync(hflags, ws.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-        RBL_HIP(hipStreamSynchronize(s));
-        if (hflags[0]) break;
+        RBL_HIP(hipGetLastError());
+        done_iters += batch;
+        rbl_spin_wait(ws.pin + 6, -1, s);
+        const volatile int* st = ws.pin + 6;
+        done = st[0];
+        iters = st[1];
+        if (done != 0) break;
+        batch = 4 * BATCH;
     }
-    RBL_HIP(hipGetLastError());
-    if (iters_host) *iters_host = hflags[1];
-    return RBL_OK;
+    if (done == 1) ws.last_fista = iters;
+    if (iters_host) *iters_host = iters;
+    return done == -1 ? RBL_ERR_HIP : RBL_OK;
 }
 
 }  // namespace
