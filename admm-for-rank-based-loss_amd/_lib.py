@@ -88,6 +88,8 @@ SIGNATURES = {
     "rbl_zd_sort_local": (C.c_int, [_P, C.c_int]),
     "rbl_zd_partition": (C.c_int, [_P, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "rbl_zd_prepare": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "rbl_zd_sort_losses": (C.c_int, [_P, C.c_int]),
+    "rbl_zd_risk": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "rbl_zd_pav": (C.c_int, [_P, C.c_void_p]),
     "rbl_zd_bounds": (C.c_int, [_P]),
     "rbl_zd_seam_setup": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_void_p]),

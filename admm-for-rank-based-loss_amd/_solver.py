@@ -260,6 +260,12 @@ class Solver:
         _lib.check(self.lib.rbl_zd_partition(self._h, C.c_void_p(splitters_ptr), int(nparts), out))
         return [int(x) for x in out]
 
+    def zd_sort_losses(self, nsamples):
+        _lib.check(self.lib.rbl_zd_sort_losses(self._h, int(nsamples)))
+
+    def zd_risk(self, n_recv, sigma_off):
+        _lib.check(self.lib.rbl_zd_risk(self._h, int(n_recv), int(sigma_off)))
+
     def zd_prepare(self, n_recv, sigma_off):
         _lib.check(self.lib.rbl_zd_prepare(self._h, int(n_recv), int(sigma_off)))
 

@@ -1293,6 +1293,43 @@ int rbl_zd_sort_local(rbl_solver* h, int nsamples) {
     return RBL_OK;
 }
 
+// the logged objective of rank weights, sum_i sigma_i loss_(i) (objective.py:73-82), needs the global
+// order of the per-sample losses: same sample sort, keys only
+int rbl_zd_sort_losses(rbl_solver* h, int nsamples) {
+    RBL_ENTER_ITER(h);
+    RBL_TRY(zd_ensure(h));
+    if (nsamples < 1 || nsamples > 256) {
+        rbl_set_error("zd_sort_losses: 1..256 samples");
+        return RBL_ERR_INVALID;
+    }
+    hipStream_t s = h->stream;
+    RBL_TRY(ensure_v(h));
+    RBL_TRY(launch_loss_keys(h->n, h->v, h->sw.keys[0], s));
+    RBL_TRY(launch_radix_sort(h->sw, h->n, false, s));
+    RBL_TRY(launch_zd_sample(h->sw.keys[0], h->n, nsamples, h->zd_small + ZD_OFF_SAMPLES, s));
+    return RBL_OK;
+}
+
+// received loss keys in RBL_BUF_ZD_RKEYS: this chunk's share of the risk -> ZD_SMALL[264]
+int rbl_zd_risk(rbl_solver* h, int64_t nrecv, int64_t sigma_off) {
+    RBL_ENTER_ITER(h);
+    RBL_TRY(zd_ensure(h));
+    if (nrecv < 0 || sigma_off < 0 || sigma_off + nrecv > h->nt) {
+        rbl_set_error("zd_risk: chunk [%lld, %lld) outside the %lld sorted positions", (long long)sigma_off,
+                      (long long)(sigma_off + nrecv), (long long)h->nt);
+        return RBL_ERR_INVALID;
+    }
+    hipStream_t s = h->stream;
+    double* out = h->zd_small + ZD_OFF_FV + 4;
+    if (nrecv == 0) {
+        RBL_HIP(hipMemsetAsync(out, 0, sizeof(double), s));
+        return RBL_OK;
+    }
+    RBL_HIP(hipMemcpyAsync(h->sw.keys[0], h->sw.keys[1], sizeof(u64) * (size_t)nrecv, hipMemcpyDeviceToDevice, s));
+    RBL_TRY(launch_radix_sort(h->sw, nrecv, false, s));
+    return launch_sorted_loss_dot(h->cfg.loss, nrecv, h->sw.keys[0], h->sigma_a + sigma_off, h->partials, out, s);
+}
+
 int rbl_zd_partition(rbl_solver* h, const void* splitters_dev, int nparts, int64_t* send_counts) {
     RBL_ENTER_ITER(h);
     if (nparts < 1 || nparts > 64 || !send_counts) return RBL_ERR_INVALID;

@@ -128,6 +128,14 @@ class GpuEngine:
         self._zd_world = splitters.numel() + 1
         return self.s.zd_partition(splitters.data_ptr(), self._zd_world)
 
+    def zd_sort_losses(self, nsamples):
+        self.s.zd_sort_losses(nsamples)
+        return self._small(0, nsamples)
+
+    def zd_risk(self, nrecv, sigma_off):
+        self.s.zd_risk(nrecv, sigma_off)
+        return self._small(264, 265)
+
     def zd_send_buffers(self):
         from . import _lib
         n = self.n_local
@@ -298,6 +306,22 @@ class ShardedADMM:
         self._alltoall(bu, back_counts, zu, bm[:, self.rank])
         e.zd_scatter(n_back)
 
+    def _risk_distributed(self):
+        """sum_i sigma_i loss_(i) (objective.py:73-82) with the sorted losses partitioned over the
+        ranks: the sample sort of the z-step on the loss keys, a dot product per chunk, one sum."""
+        e, P = self.e, self.world
+        samples_all = self._gather_small(e.zd_sort_losses(self.NS))
+        send_counts = e.zd_partition(self._splitters(samples_all, P))
+        cm = self._gather_counts(send_counts)
+        totals = cm.sum(axis=0)
+        nrecv, off = int(totals[self.rank]), int(totals[: self.rank].sum())
+        sk, _ = e.zd_send_buffers()
+        rk, _ = e.zd_recv_buffers(nrecv)
+        self._alltoall(sk, send_counts, rk, cm[:, self.rank])
+        part = e.zd_risk(nrecv, off)
+        self._allreduce(part)
+        return float(part.cpu()[0])
+
     # ------------------------------------------------------------------- one-time setup
     def setup_synthetic(self, seed=17, class_sep=1.0, flip_y=0.01):
         self.e.synth_local(seed, class_sep, flip_y)
@@ -345,5 +369,8 @@ class ShardedADMM:
         if want_objective and e.sorted_path and self.world > 1:
             # rank-weighted objective needs the global order of v: gather it (logging only);
             # phase_finish returned the regulariser alone in this case
-            st.objective += e.risk_from_v(self._allgather_rows(e.buf("v")))
+            if self.dist_z and hasattr(e, "zd_risk"):
+                st.objective += self._risk_distributed()
+            else:
+                st.objective += e.risk_from_v(self._allgather_rows(e.buf("v")))
         return st

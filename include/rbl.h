@@ -203,9 +203,14 @@ int  rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles);
  *     rbl_zd_seam_fill       pooled block value onto this rank's pooled positions
  *   rbl_zd_return_partition  (row id, value) grouped by owner into ZD_BIDS / ZD_BU; counts per owner (host)
  *   [all-to-all into ZD_ZIDS / ZD_ZU]
- *   rbl_zd_scatter           z and c = z + lambda/rho of the local rows; then rbl_phase_q as usual. */
+ *   rbl_zd_scatter           z of the local rows; then rbl_phase_q as usual.
+ * Logged objective of rank weights (sum_i sigma_i loss_(i), objective.py:73-82) by the same sample sort:
+ *   rbl_zd_sort_losses       sort the local per-sample losses (keys only) + samples; rbl_zd_partition;
+ *   [all-to-all of ZD_SKEYS into ZD_RKEYS]; rbl_zd_risk -> ZD_SMALL[264] = this chunk's share [all-reduce]. */
 int  rbl_zd_sort_local(rbl_solver* h, int nsamples);
 int  rbl_zd_partition(rbl_solver* h, const void* splitters_dev, int nparts, int64_t* send_counts);
+int  rbl_zd_sort_losses(rbl_solver* h, int nsamples);
+int  rbl_zd_risk(rbl_solver* h, int64_t n_recv, int64_t sigma_off);
 int  rbl_zd_prepare(rbl_solver* h, int64_t n_recv, int64_t sigma_off);
 int  rbl_zd_pav(rbl_solver* h, const void* fvals_total_dev);
 int  rbl_zd_bounds(rbl_solver* h);

@@ -109,6 +109,19 @@ class NumpyEngine:
             out[j] = self._zd_m[min(n - 1, ((j + 1) * n) // (nsamples + 1))] if n > nsamples else self._zd_m[j]
         return torch.from_numpy(out)
 
+    def zd_sort_losses(self, nsamples):
+        self._zd_m = np.sort(objective.sample_losses(self.loss, self.v))
+        self._zd_ids = np.zeros(self.n_local, dtype=np.int32)
+        out = np.full(nsamples, np.nan)
+        n = self.n_local
+        for j in range(min(nsamples, n)):
+            out[j] = self._zd_m[min(n - 1, ((j + 1) * n) // (nsamples + 1))] if n > nsamples else self._zd_m[j]
+        return torch.from_numpy(out)
+
+    def zd_risk(self, nrecv, sigma_off):
+        v = np.sort(self._zd_rk.numpy().view(np.float64))
+        return torch.tensor([float(np.dot(self.sa[int(sigma_off):int(sigma_off) + int(nrecv)], v))], dtype=torch.float64)
+
     def zd_partition(self, splitters):
         sp = splitters.numpy()
         dest = np.searchsorted(sp, self._zd_m, side="right")
