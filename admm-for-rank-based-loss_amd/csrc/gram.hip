@@ -16,7 +16,16 @@ constexpr int GT = 128;  // block tile
 template <typename T>
 __global__ __launch_bounds__(256) void k_gram(const T* __restrict__ D, long long n, long long ld, int ntiles,
                                                long long rows_per_split, double* __restrict__ slab) {
-    int p = blockIdx.x, ti = 0;
+    // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs by their linear id, and
+    // every XCD has its own L2.  The tile pairs of one row split read the SAME rows of D, so they
+    // are given linear ids that are equal mod 8 (gridDim.y is a multiple of 8): one XCD's L2 then
+    // serves a row to all the pairs that need it instead of every XCD fetching it from HBM.
+    const int npairs = gridDim.x;
+    const int lin = blockIdx.y * npairs + blockIdx.x;
+    const int in_xcd = lin >> 3;
+    const int split = (lin & 7) + 8 * (in_xcd / npairs);
+    const int pair = in_xcd % npairs;
+    int p = pair, ti = 0;
     while (p >= ntiles - ti) {
         p -= ntiles - ti;
         ++ti;
@@ -28,7 +37,7 @@ __global__ __launch_bounds__(256) void k_gram(const T* __restrict__ D, long long
     const long long cj0 = (long long)tj * GT + wj * 64;
     const int lk = lane >> 4;  // k (row inside the 4-row step) held by this lane
     const int lc = lane & 15;  // column inside a 16-wide MFMA operand
-    const long long r_begin = (long long)blockIdx.y * rows_per_split;
+    const long long r_begin = (long long)split * rows_per_split;
     long long r_end = r_begin + rows_per_split;
     if (r_end > n) r_end = n;
 
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(256) void k_gram(const T* __restrict__ D, long long
 
     // accumulator layout of v_mfma_f64_16x16x4_f64: register i of a lane holds row
     // 4*i + lane/16, column lane%16 (checked against numpy in tests/test_gpu_kernels.py)
-    double* tile = slab + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (GT * GT);
+    double* tile = slab + ((long long)split * npairs + pair) * (GT * GT);
 #pragma unroll
     for (int si = 0; si < 4; ++si)
 #pragma unroll
@@ -161,6 +170,7 @@ GramPlan gram_plan(long long ld, long long n, int num_cu) {
     g.rows_per_split = rps;
     g.ksplit = (int)((n + rps - 1) / rps);
     if (g.ksplit < 1) g.ksplit = 1;
+    g.ksplit = (g.ksplit + 7) / 8 * 8;   // XCD-aware placement (k_gram): splits past the last row write zero tiles
     return g;
 }
 
