@@ -408,6 +408,9 @@ def test_single_sweep_paths(loss, reg_kind):
     (300, 3100, "f64", "binary_cross_entropy", "l1_reg"),    # fp64 storage, 4 packets per thread
     (260, 7000, "f32", "binary_cross_entropy", "l2_reg"),    # 4 packets per thread, d >> n
     (1030, 900, "f64", "hinge", "l1_reg"),                   # wave-per-row kernel, 8 passes (fp64 only)
+    (901, 333, "f32", "binary_cross_entropy", "l1_reg"),     # d not a multiple of 4 (padded columns), 2 passes
+    (645, 1001, "f32", "hinge", "l2_reg"),                   # d = 1001 (the AoRR driver's intercept column), 4 passes
+    (1203, 131, "f64", "binary_cross_entropy", "l2_reg"),    # 2 passes in fp64, odd everything
 ])
 def test_single_sweep_wide_rows(rows, cols, storage, loss, reg_kind):
     """The single-sweep path for every row width (sweep_erm.hip: wave-per-row up to 4 / 8 passes,
