@@ -87,10 +87,13 @@ __global__ __launch_bounds__(256) void k_gram(const T* __restrict__ D, long long
             }
         }
     };
-    auto mfma_step = [&](const T (&a)[4], const T (&b)[4]) {
+    auto mfma_step = [&](T (&a)[4], T (&b)[4]) {
         double da[4], db[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            // opaque use of the raw registers HERE: otherwise the compiler widens all DEPTH steps at the
+            // top of the loop body and its s_waitcnt vmcnt(0) there drains the whole prefetch
+            asm volatile("" : "+v"(a[s]), "+v"(b[s]));
             da[s] = (double)a[s];
             db[s] = (double)b[s];
         }
@@ -163,14 +166,14 @@ GramPlan gram_plan(long long ld, long long n, int num_cu) {
     long long maxsplit = (n + 255) / 256;  // at least 256 rows per split
     if (want > maxsplit) want = maxsplit;
     if (want < 1) want = 1;
-    g.ksplit = (int)want;
-    long long rps = (n + g.ksplit - 1) / g.ksplit;
+    // XCD-aware placement (k_gram) deals the splits over the 8 XCDs: a multiple of 8 of them, all
+    // with rows (a split count of 1 would put the whole matrix on one XCD)
+    want = (want + 7) / 8 * 8;
+    long long rps = (n + want - 1) / want;
     rps = (rps + 7) / 8 * 8;
     if (rps < 8) rps = 8;
     g.rows_per_split = rps;
-    g.ksplit = (int)((n + rps - 1) / rps);
-    if (g.ksplit < 1) g.ksplit = 1;
-    g.ksplit = (g.ksplit + 7) / 8 * 8;   // XCD-aware placement (k_gram): splits past the last row write zero tiles
+    g.ksplit = (int)want;   // splits past the last row (tiny n) write zero tiles
     return g;
 }
 
