@@ -91,8 +91,9 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
             }
             acc[p][k] = 0.0;
         }
-        if (!ok) pkp = PK - 1;  // tail lanes re-read the last packet; w == 0 and the sums are dropped
-        boff[p] = pkp * 16;
+        // packets past the row end: an offset outside the row descriptor - the range check returns 0
+        // without a memory access (w == 0 there and the column sums are dropped)
+        boff[p] = ok ? pkp * 16 : 0x7ffffff0;
     }
     if (WL) __syncthreads();
     double s_prim = 0.0, s_zz = 0.0;
@@ -289,8 +290,9 @@ __global__ __launch_bounds__(SEW_THREADS, 1) void k_sweep_erm_wide(
             sw_wide[(p * SEW_THREADS + tid) * E + k] = ok ? w[(long long)pkp * E + k] : 0.0;
             acc[p][k] = 0.0;
         }
-        if (!ok) pkp = PK - 1;  // tail threads re-read the last packet; w == 0 and the sums are dropped
-        boff[p] = pkp * 16;
+        // packets past the row end: an offset outside the row descriptor - the range check returns 0
+        // without a memory access (w == 0 there and the column sums are dropped)
+        boff[p] = ok ? pkp * 16 : 0x7ffffff0;
     }
     double s_prim = 0.0, s_zz = 0.0;   // (each thread reads back only what it wrote: no barrier needed for sw_wide)
 
@@ -377,26 +379,38 @@ __global__ __launch_bounds__(SEW_THREADS, 1) void k_sweep_erm_wide(
         }
     };
 
-    // One copy of the row-wise code: the prefetch always lands in bufB and is moved to bufA once
-    // bufA has been consumed (R*PT register moves per batch; unrolling the loop by two instead
-    // would duplicate the inlined prox and its constants and spill).
+    // One copy of the row-wise code (unrolling by two would duplicate the inlined prox and its
+    // constants and spill): every load lands in bufB; at the top of an iteration bufB - complete by
+    // then, it was issued one whole process() earlier - is moved to bufA (R*PT register moves), the
+    // NEXT sub-batch is requested into bufB, and the arithmetic runs on bufA, whose registers are
+    // never the target of a load (so nothing in process() waits for the prefetch in flight).
     u32x4 bufA[R][PT], bufB[R][PT];
     double zo = 0.0, lm = 0.0, zoN = 0.0, lmN = 0.0;
     int q = (int)blockIdx.x, sub = 0;
     if (q < nsuper) {
-        load_side(q, zo, lm);
-        load_rows(q, 0, bufA);
+        load_side(q, zoN, lmN);
+        load_rows(q, 0, bufB);
     }
 #pragma clang loop unroll(disable)
     while (q < nsuper) {
         const int live = q == nsuper - 1 ? live_last : SR;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) bufA[r][p] = bufB[r][p];
+        if (sub == 0) {
+            zo = zoN;
+            lm = lmN;
+        }
         const bool last = sub + 1 == S;
         const int qn = last ? q + GW : q;
         const int subn = last ? 0 : sub + 1;
+        __builtin_amdgcn_sched_barrier(0);
         if (qn < nsuper) {
             if (last) load_side(qn, zoN, lmN);
             load_rows(qn, subn, bufB);
         }
+        __builtin_amdgcn_sched_barrier(0);   // the prefetch stays above the arithmetic
         process(live, sub, bufA, zo, lm);
         if (last) {
             if (tid < live) {
@@ -405,13 +419,7 @@ __global__ __launch_bounds__(SEW_THREADS, 1) void k_sweep_erm_wide(
                 if (v) v[row] = v_out;   // NULL: nobody reads v before the next pass (no objective logging)
                 z_new[row] = z_out;
             }
-            zo = zoN;
-            lm = lmN;
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int p = 0; p < PT; ++p) bufA[r][p] = bufB[r][p];
         q = qn;
         sub = subn;
     }
@@ -570,11 +578,12 @@ int launch_T(const T* D, long long n, long long ld, const double* w, const doubl
         RBL_HIP(hipGetLastError());                                                                                    \
         return RBL_OK;                                                                                                 \
     } while (0)
+    if (pt <= 1) RBL_WIDE(1, 16, 1);
     if (pt <= 2) RBL_WIDE(2, 4, 4);
     if (pt <= 3) RBL_WIDE(3, 4, 4);
     if (pt <= 4) RBL_WIDE(4, 2, 8);
     if (pt <= 5) RBL_WIDE(5, 2, 8);
-    if (pt <= 6) RBL_WIDE(6, 2, 8);
+    if (pt <= 6) RBL_WIDE(6, 1, 16);
     if (pt <= 8) RBL_WIDE(8, 1, 16);
 #undef RBL_WIDE
     rbl_set_error("single-sweep kernel: d=%lld too wide", (long long)ld);
