@@ -57,7 +57,7 @@ __device__ inline void opaque(u32x4 (&buf)[R][P]) {
 // only - the z-step needs the global sort and q a second pass); the other values exist for
 // tools/sweep_lab.hip (ablation timings: which phase costs what).
 constexpr int SE_VONLY = 2 | 4 | 128;   // no accumulation phase, no prox, no z' / slab output
-template <typename T, int LOSS, int P, int R, int S, bool WL, int EXP = 0>
+template <typename T, int LOSS, int P, int R, int S, bool WL, int EXP = 0, bool ONE = false>
 __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
     const T* __restrict__ D, long long n, long long ld, const double* __restrict__ w, const double* __restrict__ z_old,
     double* __restrict__ lam, double* __restrict__ v, double* __restrict__ z_new, double sigma0, double rho,
@@ -193,6 +193,46 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
     u32x4 bufA[R][P], bufB[R][P];
     double zo = 0.0, lm = 0.0, zoN = 0.0, lmN = 0.0;
     int q = gw, sub = 0;
+    if (ONE) {
+        // One copy of the row-wise code, as in k_sweep_erm_wide: every load lands in bufB; at the
+        // top of an iteration bufB (issued one whole process() earlier) is moved to bufA, the next
+        // sub-batch is requested into bufB and the arithmetic runs on bufA, whose registers are
+        // never the target of a load - nothing in process() waits for the prefetch in flight.
+        if (q < nsuper) {
+            load_side(q, zoN, lmN);
+            load_rows(q, 0, bufB);
+        }
+#pragma clang loop unroll(disable)
+        while (q < nsuper) {
+            const int live = q == nsuper - 1 ? live_last : SR;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int p = 0; p < P; ++p) bufA[r][p] = bufB[r][p];
+            if (sub == 0) {
+                zo = zoN;
+                lm = lmN;
+            }
+            const bool last = sub + 1 == S;
+            const int qn = last ? q + GW : q;
+            const int subn = last ? 0 : sub + 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (qn < nsuper) {
+                if (last) load_side(qn, zoN, lmN);
+                load_rows(qn, subn, bufB);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the prefetch stays above the arithmetic
+            process(live, sub, bufA, zo, lm);
+            if (last && lane < live && !(EXP & 1)) {
+                const long long row = (long long)q * SR + lane;
+                lam[row] = l_out;
+                if (v) v[row] = v_out;   // NULL: nobody reads v before the next pass (no objective logging)
+                if (!(EXP & 128)) z_new[row] = z_out;
+            }
+            q = qn;
+            sub = subn;
+        }
+    } else {
     if (q < nsuper) {
         load_side(q, zo, lm);
         load_rows(q, 0, bufA);
@@ -224,6 +264,7 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
         }
         q = qn;
         sub = subn;
+    }
     }
 
     // fold the 4 waves' column sums in LDS, one slab row per block
@@ -541,7 +582,7 @@ template <typename T, int LOSS, int P, int R, int S, bool WL>
 int launch_one(const T* D, long long n, long long ld, const double* w, const double* z_old, double* lam, double* v,
                double* z_new, double sigma0, double rho, const double* pred, double* slab, double* partials, int grid,
                hipStream_t s) {
-    hipLaunchKernelGGL((k_sweep_erm<T, LOSS, P, R, S, WL>), dim3(grid), dim3(SE_THREADS), 0, s, D, n, ld, w, z_old, lam, v,
+    hipLaunchKernelGGL((k_sweep_erm<T, LOSS, P, R, S, WL, 0, true>), dim3(grid), dim3(SE_THREADS), 0, s, D, n, ld, w, z_old, lam, v,
                        z_new, sigma0, rho, pred, slab, partials);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
@@ -658,7 +699,7 @@ int launch_v_T(const T* D, long long n, long long ld, const double* w, const dou
     const long long passes = (PK + 63) / 64;
 #define RBL_V(P_, R_, S_)                                                                                           \
     do {                                                                                                            \
-        hipLaunchKernelGGL((k_sweep_erm<T, 1, P_, R_, S_, false, SE_VONLY>), dim3(grid), dim3(SE_THREADS), 0, s, D, n, \
+        hipLaunchKernelGGL((k_sweep_erm<T, 1, P_, R_, S_, false, SE_VONLY, true>), dim3(grid), dim3(SE_THREADS), 0, s, D, n, \
                            ld, w, z, lam, v, (double*)nullptr, 0.0, rho, (const double*)nullptr, (double*)nullptr,  \
                            partials);                                                                               \
         RBL_HIP(hipGetLastError());                                                                                 \

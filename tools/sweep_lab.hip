@@ -11,7 +11,7 @@ int launch_sum_partials(const double*, int, int, double*, hipStream_t) { return 
 int launch_loss_sum(int, int64_t, const double*, double, double*, double*, hipStream_t) { return 0; }
 void rbl_set_error(const char*, ...) {}
 
-template <int P, int R, int S, bool WL, int EXP>
+template <int P, int R, int S, bool WL, int EXP, bool ONE = false>
 static void run(const char* name, const float* D, long long n, long long ld, double* w, double* z, double* lam, double* v,
                 double* zn, double* pred, double* slab, double* partials, int grid) {
     hipEvent_t e0, e1;
@@ -21,7 +21,7 @@ static void run(const char* name, const float* D, long long n, long long ld, dou
     const int reps = 6;
     for (int i = 0; i < reps + 1; ++i) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((k_sweep_erm<float, 0, P, R, S, WL, EXP>), dim3(grid), dim3(SE_THREADS), 0, 0, D, n, ld, w, z, lam, v, zn,
+        hipLaunchKernelGGL((k_sweep_erm<float, 0, P, R, S, WL, EXP, ONE>), dim3(grid), dim3(SE_THREADS), 0, 0, D, n, ld, w, z, lam, v, zn,
                            1.0, 1e-3, pred, slab, partials);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
@@ -29,7 +29,7 @@ static void run(const char* name, const float* D, long long n, long long ld, dou
         hipEventElapsedTime(&ms, e0, e1);
         if (i) { tot += ms; best = ms < best ? ms : best; }
     }
-    printf("%-34s P=%d R=%d S=%d WL=%d EXP=%2d grid=%4d  avg %.3f ms  best %.3f ms  %.0f GB/s\n", name, P, R, S, (int)WL, EXP, grid,
+    printf("%-34s P=%d R=%d S=%d WL=%d ONE=%d EXP=%2d grid=%4d  avg %.3f ms  best %.3f ms  %.0f GB/s\n", name, P, R, S, (int)WL, (int)ONE, EXP, grid,
            tot / reps, best, (double)n * ld * 4 / (tot / reps) * 1e-6);
     fflush(stdout);
 }
@@ -52,10 +52,14 @@ int main(int argc, char** argv) {
     hipGetDeviceProperties(&prop, 0);
     const int cu = prop.multiProcessorCount;
 #define RUN(name, P, R, S, WL, EXP, grid) run<P, R, S, WL, EXP>(name, D, n, ld, w, z, lam, v, zn, pred, slab, partials, grid)
-    RUN("full (library) R=2 S=8 regs", 4, 2, 8, false, 0, 2 * cu);
-    RUN("no row writes", 4, 2, 8, false, 1, 2 * cu);
-    RUN("no zo/lm loads, no prox", 4, 2, 8, false, 32 | 4, 2 * cu);
-    RUN("no writes/prox/zo", 4, 2, 8, false, 1 | 4 | 32, 2 * cu);
-    RUN("loads only", 4, 2, 8, false, 1 | 2 | 4 | 8 | 16 | 32, 2 * cu);
+    RUN("full (library) two-copy R=2 S=8", 4, 2, 8, false, 0, 2 * cu);
+#define RUN1(name, P, R, S, WL, EXP, grid) run<P, R, S, WL, EXP, true>(name, D, n, ld, w, z, lam, v, zn, pred, slab, partials, grid)
+    RUN1("one-copy (move at top) R=2 S=8", 4, 2, 8, false, 0, 2 * cu);
+    RUN1("one-copy R=4 S=4 regs", 4, 4, 4, false, 0, 2 * cu);
+    RUN1("one-copy R=4 S=4 w in LDS", 4, 4, 4, true, 0, 2 * cu);
+    RUN1("one-copy R=2 S=8, 3 blocks per 2 CUs", 4, 2, 8, false, 0, cu * 3 / 2);
+    RUN1("one-copy loads only", 4, 2, 8, false, 1 | 2 | 4 | 8 | 16 | 32, 2 * cu);
+    RUN("no row writes (two-copy)", 4, 2, 8, false, 1, 2 * cu);
+    RUN("loads only (two-copy)", 4, 2, 8, false, 1 | 2 | 4 | 8 | 16 | 32, 2 * cu);
     return 0;
 }
