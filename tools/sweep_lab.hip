@@ -52,14 +52,18 @@ int main(int argc, char** argv) {
     hipGetDeviceProperties(&prop, 0);
     const int cu = prop.multiProcessorCount;
 #define RUN(name, P, R, S, WL, EXP, grid) run<P, R, S, WL, EXP>(name, D, n, ld, w, z, lam, v, zn, pred, slab, partials, grid)
-    RUN("full (library) two-copy R=2 S=8", 4, 2, 8, false, 0, 2 * cu);
 #define RUN1(name, P, R, S, WL, EXP, grid) run<P, R, S, WL, EXP, true>(name, D, n, ld, w, z, lam, v, zn, pred, slab, partials, grid)
-    RUN1("one-copy (move at top) R=2 S=8", 4, 2, 8, false, 0, 2 * cu);
-    RUN1("one-copy R=4 S=4 regs", 4, 4, 4, false, 0, 2 * cu);
-    RUN1("one-copy R=4 S=4 w in LDS", 4, 4, 4, true, 0, 2 * cu);
-    RUN1("one-copy R=2 S=8, 3 blocks per 2 CUs", 4, 2, 8, false, 0, cu * 3 / 2);
-    RUN1("one-copy loads only", 4, 2, 8, false, 1 | 2 | 4 | 8 | 16 | 32, 2 * cu);
-    RUN("no row writes (two-copy)", 4, 2, 8, false, 1, 2 * cu);
-    RUN("loads only (two-copy)", 4, 2, 8, false, 1 | 2 | 4 | 8 | 16 | 32, 2 * cu);
+    RUN1("full (library)", 4, 2, 8, false, 0, 2 * cu);
+    RUN("full, two-copy loop", 4, 2, 8, false, 0, 2 * cu);
+    RUN1("full, 1 block/CU", 4, 2, 8, false, 0, cu);
+    RUN1("full, R=4 S=4 w in LDS", 4, 4, 4, true, 0, 2 * cu);
+    RUN1("v-only (rank-weighted problems)", 4, 2, 8, false, SE_VONLY, 2 * cu);
+    RUN1("no row writes", 4, 2, 8, false, 1, 2 * cu);
+    RUN1("no acc phase", 4, 2, 8, false, 2, 2 * cu);
+    RUN1("no prox", 4, 2, 8, false, 4, 2 * cu);
+    RUN1("no wave reduce", 4, 2, 8, false, 8, 2 * cu);
+    RUN1("no dot", 4, 2, 8, false, 16, 2 * cu);
+    RUN1("loads only", 4, 2, 8, false, 1 | 2 | 4 | 8 | 16 | 32, 2 * cu);
+    RUN1("loads only, 4 blocks/CU", 4, 2, 8, false, 1 | 2 | 4 | 8 | 16 | 32, 4 * cu);
     return 0;
 }
