@@ -600,30 +600,70 @@ int rbl_set_data(rbl_solver* h, const double* X, const double* y, int64_t ldx) {
     }
     const int64_t n = h->n, d = h->d;
     if (n > 0) {
+        // The caller's rows are pinned in place for the duration of the call (hipHostRegister), so the
+        // 64 MB chunks go over PCIe by DMA at link speed, and two staging buffers let the copy of chunk
+        // k+1 run (second stream) while chunk k is converted to the storage type into D.  If the
+        // pages cannot be pinned the chunks are copied from pageable memory instead (slower, same result).
         int64_t chunk = (int64_t)((64LL << 20) / (sizeof(double) * (size_t)ldx));
         if (chunk < 1) chunk = 1;
         if (chunk > n) chunk = n;
-        double *Xd = nullptr, *yd = nullptr;
-        RBL_TRY(dev_alloc(&Xd, (size_t)chunk * ldx));
-        if (dev_alloc(&yd, (size_t)chunk) != RBL_OK) {
-            dev_free(Xd);
+        const size_t xbytes = sizeof(double) * (size_t)n * (size_t)ldx;
+        const bool pinned = hipHostRegister(const_cast<double*>(X), xbytes, hipHostRegisterDefault) == hipSuccess;
+        if (!pinned) (void)hipGetLastError();
+        double *Xd[2] = {nullptr, nullptr}, *yd = nullptr;
+        hipStream_t copy_stream = nullptr;
+        hipEvent_t copied[2] = {nullptr, nullptr}, formed[2] = {nullptr, nullptr};
+        int rc = RBL_OK;
+        auto cleanup = [&]() {
+            dev_free(Xd[0]); dev_free(Xd[1]); dev_free(yd);
+            for (int k = 0; k < 2; ++k) {
+                if (copied[k]) (void)hipEventDestroy(copied[k]);
+                if (formed[k]) (void)hipEventDestroy(formed[k]);
+            }
+            if (copy_stream) (void)hipStreamDestroy(copy_stream);
+            if (pinned) (void)hipHostUnregister(const_cast<double*>(X));
+        };
+        if (dev_alloc(&Xd[0], (size_t)chunk * ldx) != RBL_OK || dev_alloc(&Xd[1], (size_t)chunk * ldx) != RBL_OK ||
+            dev_alloc(&yd, (size_t)n) != RBL_OK) {
+            cleanup();
             return RBL_ERR_NOMEM;
         }
-        int rc = RBL_OK;
-        for (int64_t r0 = 0; r0 < n && rc == RBL_OK; r0 += chunk) {
+        bool ok = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; k < 2 && ok; ++k)
+            ok = hipEventCreateWithFlags(&copied[k], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&formed[k], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipMemcpyAsync(yd, y, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
+        if (!ok) {
+            rbl_set_error("set_data: stream / event / label upload failed: %s", hipGetErrorString(hipGetLastError()));
+            cleanup();
+            return RBL_ERR_HIP;
+        }
+        int64_t k = 0;
+        for (int64_t r0 = 0; r0 < n && rc == RBL_OK; r0 += chunk, ++k) {
             const int64_t rows = n - r0 < chunk ? n - r0 : chunk;
-            hipError_t e = hipMemcpyAsync(Xd, X + r0 * ldx, sizeof(double) * rows * ldx, hipMemcpyHostToDevice, h->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(yd, y + r0, sizeof(double) * rows, hipMemcpyHostToDevice, h->stream);
+            const int b = (int)(k & 1);
+            hipError_t e = hipSuccess;
+            if (k >= 2) e = hipStreamWaitEvent(copy_stream, formed[b], 0);   // staging buffer b has been consumed
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(Xd[b], X + r0 * ldx, sizeof(double) * rows * ldx, hipMemcpyHostToDevice, copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(copied[b], copy_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, copied[b], 0);
             if (e != hipSuccess) {
                 rbl_set_error("set_data: upload failed: %s", hipGetErrorString(e));
                 rc = RBL_ERR_HIP;
                 break;
             }
-            rc = launch_form_D(h->storage, h->D, h->ld, r0, Xd, ldx, yd, rows, d, h->stream);
-            if (rc == RBL_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = RBL_ERR_HIP;
+            rc = launch_form_D(h->storage, h->D, h->ld, r0, Xd[b], ldx, yd + r0, rows, d, h->stream);
+            if (rc == RBL_OK && hipEventRecord(formed[b], h->stream) != hipSuccess) rc = RBL_ERR_HIP;
         }
-        dev_free(Xd);
-        dev_free(yd);
+        if (hipStreamSynchronize(copy_stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+            if (rc == RBL_OK) {
+                rbl_set_error("set_data: %s", hipGetErrorString(hipGetLastError()));
+                rc = RBL_ERR_HIP;
+            }
+        }
+        cleanup();
         RBL_TRY(rc);
         std::vector<signed char> ys((size_t)n);
         for (int64_t i = 0; i < n; ++i) ys[(size_t)i] = y[i] > 0 ? 1 : -1;
