@@ -41,6 +41,10 @@ CONFIGS = {
                     args=None, B=None, label="SRM erm / BCE / l1=0.01, synthetic 1250000x10000 dense"),
     "C2hinge": dict(rows=6_000_000, cols=1000, weight_function="erm", loss="hinge", wstep=1, reg=0.01,
                     args=None, B=None, label="SRM erm / hinge / l1=0.01, synthetic 6000000x1000"),
+    "C2smooth": dict(rows=6_000_000, cols=1000, weight_function="erm", loss="binary_cross_entropy", wstep=3, reg=0.01,
+                     args=None, B=None, label="sADMM erm / BCE / smoothed l1=0.01, synthetic 6000000x1000"),
+    "C2l2": dict(rows=6_000_000, cols=1000, weight_function="erm", loss="binary_cross_entropy", wstep=2, reg=0.01,
+                 args=None, B=None, label="SRM erm / BCE / l2=0.01, synthetic 6000000x1000"),
     "C2sq": dict(rows=6_000_000, cols=1000, weight_function="superquantile", loss="binary_cross_entropy", wstep=2,
                  reg=0.01, args=[0.5], B=None, label="SRM superquantile(0.5) / BCE / l2=0.01, synthetic 6000000x1000"),
 }
