@@ -645,7 +645,14 @@ static bool sweep_erm_is_wide(int storage, int64_t ld) {
     return PK > (storage == RBL_STORE_F32 ? 256 : 512);
 }
 
-int sweep_erm_blocks(int num_cu) { return num_cu * 2; }  // 2 blocks of 4 waves per CU (2 waves per SIMD)
+int sweep_erm_blocks(int num_cu) {   // 2 blocks of 4 waves per CU (2 waves per SIMD); RBL_SWEEP_BLOCKS_PER_CU=1 for experiments
+    static const int per_cu = [] {
+        const char* e = getenv("RBL_SWEEP_BLOCKS_PER_CU");
+        const int v = e ? atoi(e) : 2;
+        return (v == 1 || v == 2) ? v : 2;
+    }();
+    return num_cu * per_cu;
+}
 int sweep_erm_slab_rows(int num_cu) { return sweep_erm_blocks(num_cu) + CR_SLICES; }
 
 int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld, const double* w, const double* z_old,
