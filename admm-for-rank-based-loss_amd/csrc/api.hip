@@ -336,11 +336,14 @@ int z_step_sorted(rbl_solver* h, const double* msrc, double rho) {
     RBL_TRY(launch_unflip_keys(nt, h->sw.keys[0], h->pw.ms, s));
     RBL_TRY(launch_prefix(h->pw.ms, nt, h->pw.locx_m, h->pw.chunk_m, h->pw.cph_m, h->pw.cpl_m, s));
     const bool ehrm = h->cfg.weight_function == RBL_W_EHRM;
+    // EHRM: the branch test solves both element prox problems; they are level 0 of the tree as well
+    double* u0a = ehrm ? h->pw.u : nullptr;
+    double* u0b = ehrm ? (double*)h->sw.keys[1] : nullptr;   // free once the sort is done
     if (ehrm)
         RBL_TRY(launch_ehrm_branch(nt, h->sigma_a, h->sigma_b, h->cfg.B, rho, h->pw.ms, h->pw.partials, h->pw.branch,
-                                   -1, s));
+                                   -1, s, u0a, u0b));
     RBL_TRY(launch_pav_tree(h->cfg.loss, nt, rho, h->pw.ms, h->sigma_a, h->sigma_b, h->pw.u, h->pa, h->pb, h->pm,
-                            ehrm ? h->pw.branch : nullptr, h->pw.recs, h->pw.counters, s));
+                            ehrm ? h->pw.branch : nullptr, h->pw.recs, h->pw.counters, s, u0a, u0b));
     RBL_TRY(launch_scatter_z(nt, h->pw.u, h->sw.vals[0], ehrm ? h->pw.branch : nullptr, h->cfg.B, ehrm ? 1 : 0, rho,
                              h->lam, h->z, nullptr, h->off, h->n, s));
     return RBL_OK;
@@ -1416,7 +1419,7 @@ int rbl_zd_prepare(rbl_solver* h, int64_t nrecv, int64_t sigma_off) {
     if (ehrm) {
         RBL_TRY(launch_prefix(h->sigma_b + sigma_off, nrecv, h->zd_locx_b, h->zd_chunk_b, h->zd_cph_b, h->zd_cpl_b, s));
         RBL_TRY(launch_ehrm_fvals(nrecv, h->sigma_a + sigma_off, h->sigma_b + sigma_off, h->cfg.B, h->step_rho, h->pw.ms,
-                                  h->pw.partials, fv, s));
+                                  h->pw.partials, fv, s, h->pw.u, (double*)h->sw.keys[1]));
     } else {
         RBL_HIP(hipMemsetAsync(fv, 0, 2 * sizeof(double), s));
     }
@@ -1430,7 +1433,8 @@ int rbl_zd_pav(rbl_solver* h, const void* fvals_total_dev) {
     if (ehrm) RBL_TRY(launch_ehrm_pick((const double*)fvals_total_dev, h->pw.branch, s));
     const Prefix pm{h->pw.locx_m, h->pw.cph_m, h->pw.cpl_m};
     RBL_TRY(launch_pav_tree(h->cfg.loss, h->zd_n, h->step_rho, h->pw.ms, h->sigma_a + h->zd_off, h->sigma_b + h->zd_off,
-                            h->pw.u, h->zpa, h->zpb, pm, ehrm ? h->pw.branch : nullptr, h->pw.recs, h->pw.counters, s));
+                            h->pw.u, h->zpa, h->zpb, pm, ehrm ? h->pw.branch : nullptr, h->pw.recs, h->pw.counters, s,
+                            ehrm ? h->pw.u : nullptr, ehrm ? (const double*)h->sw.keys[1] : nullptr));
     return RBL_OK;
 }
 

@@ -360,8 +360,11 @@ constexpr int PB_PER = PB_TILE / PV_THREADS;
 template <int LOSS>
 __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restrict__ ms, const double* __restrict__ sa,
                                                             const double* __restrict__ sb, const int* __restrict__ branch,
-                                                            double rho, long long n, double* __restrict__ u_out,
-                                                            u32* __restrict__ merge_counter) {
+                                                            double rho, long long n, double* u_out,
+                                                            u32* __restrict__ merge_counter, const double* u0a,
+                                                            const double* u0b) {
+    // u0a / u0b != NULL (EHRM): level 0 was computed by k_ehrm_fvals; u0a may alias u_out (a block reads
+    // and writes only its own tile)
     __shared__ double su[PB_TILE];
     __shared__ double spa[PB_TILE + 1];
     __shared__ double spm[PB_TILE + 1];
@@ -369,6 +372,7 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long base = (long long)blockIdx.x * PB_TILE;
     const double* sg = (branch && *branch) ? sb : sa;
+    const double* u0 = u0a ? ((branch && *branch) ? u0b : u0a) : nullptr;
     long long nt = n - base;  // valid positions of this tile
     if (nt > PB_TILE) nt = PB_TILE;
 
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
         const bool ok = i < nt;
         ls[k] = ok ? sg[base + i] : 0.0;
         lm[k] = ok ? ms[base + i] : 0.0;
-        su[i] = ok ? rbl::prox<LOSS>(ls[k], rho, lm[k]) : 0.0;
+        su[i] = ok ? (u0 ? u0[base + i] : rbl::prox<LOSS>(ls[k], rho, lm[k])) : 0.0;
         ts += ls[k];
         tm += lm[k];
     }
@@ -514,15 +518,22 @@ __global__ void k_unflip(long long n, const u64* __restrict__ keys, double* __re
 __global__ __launch_bounds__(PV_THREADS) void k_ehrm_fvals(long long n, const double* __restrict__ sa,
                                                             const double* __restrict__ sb, double B, double rho,
                                                             const double* __restrict__ ms,
-                                                            double* __restrict__ partials) {
+                                                            double* __restrict__ partials, double* __restrict__ u0a,
+                                                            double* __restrict__ u0b) {
+    // u0a / u0b (optional): the element prox of both branches, which is also level 0 of the PAV tree of
+    // whichever branch wins - kept so that k_pav_bottom does not solve n Newton problems again
     __shared__ double smem[2 * PV_THREADS / 64];
     double acc[2] = {0.0, 0.0};
     for (long long i = (long long)blockIdx.x * PV_THREADS + threadIdx.x; i < n;
          i += (long long)gridDim.x * PV_THREADS) {
         const double m = ms[i];
         double o1 = rbl::prox_bce(sa[i], rho, m);
-        if (o1 > B) o1 = B;
         double o2 = rbl::prox_bce(sb[i], rho, m);
+        if (u0a) {
+            u0a[i] = o1;
+            u0b[i] = o2;
+        }
+        if (o1 > B) o1 = B;
         if (o2 <= B) o2 = B;
         acc[0] += sa[i] * rbl::softplus(o1) + 0.5 * rho * (o1 - m) * (o1 - m);
         acc[1] += sb[i] * rbl::softplus(o2) + 0.5 * rho * (o2 - m) * (o2 - m);
@@ -849,9 +860,9 @@ int launch_unflip_keys(int64_t n, const u64* keys, double* ms, hipStream_t s) {
 }
 
 int launch_ehrm_branch(int64_t n, const double* sa, const double* sb, double B, double rho, const double* ms,
-                       double* partials, int* branch, int forced, hipStream_t s) {
+                       double* partials, int* branch, int forced, hipStream_t s, double* u0a, double* u0b) {
     const int nb = reduce_blocks();
-    hipLaunchKernelGGL(k_ehrm_fvals, dim3(nb), dim3(PV_THREADS), 0, s, (long long)n, sa, sb, B, rho, ms, partials);
+    hipLaunchKernelGGL(k_ehrm_fvals, dim3(nb), dim3(PV_THREADS), 0, s, (long long)n, sa, sb, B, rho, ms, partials, u0a, u0b);
     hipLaunchKernelGGL(k_ehrm_pick, dim3(1), dim3(256), 0, s, partials, nb, forced, branch);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
@@ -859,9 +870,9 @@ int launch_ehrm_branch(int64_t n, const double* sa, const double* sb, double B, 
 
 // the two singleton-stage sums of this chunk alone -> out2 (summed over ranks by the caller)
 int launch_ehrm_fvals(int64_t n, const double* sa, const double* sb, double B, double rho, const double* ms,
-                      double* partials, double* out2, hipStream_t s) {
+                      double* partials, double* out2, hipStream_t s, double* u0a, double* u0b) {
     const int nb = reduce_blocks();
-    hipLaunchKernelGGL(k_ehrm_fvals, dim3(nb), dim3(PV_THREADS), 0, s, (long long)n, sa, sb, B, rho, ms, partials);
+    hipLaunchKernelGGL(k_ehrm_fvals, dim3(nb), dim3(PV_THREADS), 0, s, (long long)n, sa, sb, B, rho, ms, partials, u0a, u0b);
     RBL_HIP(hipGetLastError());
     return launch_sum_partials(partials, nb, 2, out2, s);
 }
@@ -901,17 +912,17 @@ int launch_add_u32(int64_t n, u32* x, u32 add, hipStream_t s) {
 
 int launch_pav_tree(int loss, int64_t n, double rho, const double* ms, const double* sa, const double* sb, double* u,
                     Prefix pa, Prefix pb, Prefix pm, const int* branch, SeamRec* recs, u32* merge_counter,
-                    hipStream_t s) {
+                    hipStream_t s, const double* u0a, const double* u0b) {
     RBL_HIP(hipMemsetAsync(merge_counter, 0, sizeof(u32), s));
     if (n <= 0) return RBL_OK;
     // levels 0 .. log2(PB_TILE): prox + in-LDS merges, one tile per workgroup
     const unsigned tiles = (unsigned)((n + PB_TILE - 1) / PB_TILE);
     if (loss == RBL_LOSS_BCE)
         hipLaunchKernelGGL(k_pav_bottom<0>, dim3(tiles), dim3(PV_THREADS), 0, s, ms, sa, sb, branch, rho, (long long)n, u,
-                           merge_counter);
+                           merge_counter, u0a, u0b);
     else
         hipLaunchKernelGGL(k_pav_bottom<1>, dim3(tiles), dim3(PV_THREADS), 0, s, ms, sa, sb, branch, rho, (long long)n, u,
-                           merge_counter);
+                           merge_counter, u0a, u0b);
     // upper levels: one WAVE per seam (64-ary inner searches), pooled ranges written by a fill pass
     static const bool thread_seams = [] {
         const char* e = getenv("RBL_PAV_THREAD_SEAMS");   // the one-thread-per-seam kernel, for comparison

@@ -125,13 +125,16 @@ int launch_prefix(const double* x, int64_t n, double* locx, double* chunk_tot, d
                   hipStream_t s);
 int launch_unflip_keys(int64_t n, const u64* keys, double* ms, hipStream_t s);
 // EHRM: scalar branch test (PAV_cpt.py:205-226) -> *branch
+// u0a / u0b (optional): the element prox of both branches is kept for launch_pav_tree
 int launch_ehrm_branch(int64_t n, const double* sa, const double* sb, double B, double rho, const double* ms,
-                       double* partials, int* branch, int forced, hipStream_t s);
+                       double* partials, int* branch, int forced, hipStream_t s, double* u0a = nullptr,
+                       double* u0b = nullptr);
 // element prox (level 0) + merge tree -> u.  sigma = sa, or sb when *branch != 0 (EHRM); the
 // matching prefix sums are pa / pb.
+// u0a / u0b != NULL: level 0 (element prox of branch a / b) was computed already; u0a may alias u
 int launch_pav_tree(int loss, int64_t n, double rho, const double* ms, const double* sa, const double* sb, double* u,
                     Prefix pa, Prefix pb, Prefix pm, const int* branch, SeamRec* recs, u32* merge_counter,
-                    hipStream_t s);
+                    hipStream_t s, const double* u0a = nullptr, const double* u0b = nullptr);
 // z[perm[i]] = clip(u[i]); c[perm[i]] = z + lam[perm[i]]/rho  (local slice [off, off+nloc))
 // ---- distributed z-step (merge tree over ranks; pav.hip, CPU restatement oracle/zdist.py)
 struct ZdSeam {
@@ -140,7 +143,7 @@ struct ZdSeam {
     double x, cnt;                 // pooled block: value and length
 };
 int launch_ehrm_fvals(int64_t n, const double* sa, const double* sb, double B, double rho, const double* ms,
-                      double* partials, double* out2, hipStream_t s);
+                      double* partials, double* out2, hipStream_t s, double* u0a = nullptr, double* u0b = nullptr);
 int launch_ehrm_pick(const double* fvals_total, int* branch, hipStream_t s);
 int launch_add_u32(int64_t n, u32* x, u32 add, hipStream_t s);
 int launch_make_c(int64_t n, const double* z, const double* lam, double rho, double* c, hipStream_t s);
