@@ -424,10 +424,19 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
 
     const LdsAcc ac{su, spa, spm};
     u32 merges = 0;
+    // Levels with short segments: the thread that merged a seam writes the pooled range itself.
+    // From PB_COOP on (at most PB_TILE / (2 PB_COOP) seams per level) the pooled ranges get long
+    // (up to the whole tile) and a single thread writing them would serialise the level: the
+    // seam threads only record (s*, e*, x) and the whole workgroup writes.
+    constexpr int PB_COOP = 32;
+    __shared__ int rec_s[PB_TILE / (2 * PB_COOP)], rec_e[PB_TILE / (2 * PB_COOP)];
+    __shared__ double rec_x[PB_TILE / (2 * PB_COOP)];
     for (int half = 1; half < PB_TILE; half <<= 1) {
         const int nseams = PB_TILE / (2 * half);
+        const bool coop = half >= PB_COOP;
         for (int k = tid; k < nseams; k += PV_THREADS) {
             const long long seam = (2LL * k + 1) * half;
+            if (coop) rec_s[k] = -1;
             if (seam >= nt) continue;
             if (su[seam - 1] <= su[seam]) continue;  // pav.py:105: only a strict decrease violates
             long long R1 = seam + half;
@@ -435,10 +444,25 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
             long long s_star, e_star;
             double x;
             seam_merge<LOSS>(ac, seam - half, seam, R1, rho, s_star, e_star, x);
-            for (long long i = s_star; i <= e_star; ++i) su[i] = x;  // disjoint from other seams' segments
+            if (coop) {
+                rec_s[k] = (int)s_star;
+                rec_e[k] = (int)e_star;
+                rec_x[k] = x;
+            } else {
+                for (long long i = s_star; i <= e_star; ++i) su[i] = x;  // disjoint from other seams' segments
+            }
             ++merges;
         }
         __syncthreads();
+        if (coop) {
+            const int shift = 31 - __clz(2 * half);   // log2 of the segment length
+            for (int i = tid; i < nt; i += PV_THREADS) {
+                const int k = i >> shift;
+                const int s0 = rec_s[k];
+                if (s0 >= 0 && i >= s0 && i <= rec_e[k]) su[i] = rec_x[k];
+            }
+            __syncthreads();
+        }
     }
     for (int i = tid; i < nt; i += PV_THREADS) u_out[base + i] = su[i];
     if (merges) atomicAdd(merge_counter, merges);
