@@ -216,6 +216,7 @@ __device__ inline long long wave_first(const double* __restrict__ u, long long l
         pred = STRICT ? (x > t) : (x >= t);
     }
     const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return hi;   // exactly 64 positions left and none satisfies the predicate
     const long long r = lo + (__ffsll((long long)mask) - 1);
     return r < hi ? r : hi;
 }
@@ -223,6 +224,22 @@ __device__ inline long long upper_bound_gt(const WaveAcc& ac, long long lo, long
     return lo < hi ? wave_first<true>(ac.u, lo, hi, t) : lo;
 }
 __device__ inline long long lower_bound_ge(const WaveAcc& ac, long long lo, long long hi, double t) {
+    return lo < hi ? wave_first<false>(ac.u, lo, hi, t) : lo;
+}
+
+// the same for a tile in LDS (top levels of k_pav_bottom: 4, 2, 1 seams per tile, one wave each)
+struct WaveLdsAcc {
+    const double* u;
+    const double* pa;
+    const double* pm;
+    __device__ inline double val(long long i) const { return u[i]; }
+    __device__ inline double sum_a(long long s, long long e1) const { return pa[e1] - pa[s]; }
+    __device__ inline double sum_m(long long s, long long e1) const { return pm[e1] - pm[s]; }
+};
+__device__ inline long long upper_bound_gt(const WaveLdsAcc& ac, long long lo, long long hi, double t) {
+    return lo < hi ? wave_first<true>(ac.u, lo, hi, t) : lo;
+}
+__device__ inline long long lower_bound_ge(const WaveLdsAcc& ac, long long lo, long long hi, double t) {
     return lo < hi ? wave_first<false>(ac.u, lo, hi, t) : lo;
 }
 
@@ -362,7 +379,7 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
                                                             const double* __restrict__ sb, const int* __restrict__ branch,
                                                             double rho, long long n, double* u_out,
                                                             u32* __restrict__ merge_counter, const double* u0a,
-                                                            const double* u0b) {
+                                                            const double* u0b, int wave_top) {
     // u0a / u0b != NULL (EHRM): level 0 was computed by k_ehrm_fvals; u0a may alias u_out (a block reads
     // and writes only its own tile)
     __shared__ double su[PB_TILE];
@@ -434,6 +451,30 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
     for (int half = 1; half < PB_TILE; half <<= 1) {
         const int nseams = PB_TILE / (2 * half);
         const bool coop = half >= PB_COOP;
+        if (wave_top && nseams <= PV_THREADS / 64) {
+            // top levels of the tile: one WAVE per seam, 64-ary searches in LDS
+            const int k = wave;
+            if (k < nseams) {
+                const long long seam = (2LL * k + 1) * half;
+                bool act = seam < nt;
+                if (act) act = su[seam - 1] > su[seam];   // pav.py:105: only a strict decrease violates
+                if (lane == 0) rec_s[k] = -1;
+                if (act) {
+                    long long R1 = seam + half;
+                    if (R1 > nt) R1 = nt;
+                    long long s_star, e_star;
+                    double x;
+                    const WaveLdsAcc wac{su, spa, spm};
+                    seam_merge<LOSS>(wac, seam - half, seam, R1, rho, s_star, e_star, x);
+                    if (lane == 0) {
+                        rec_s[k] = (int)s_star;
+                        rec_e[k] = (int)e_star;
+                        rec_x[k] = x;
+                        ++merges;
+                    }
+                }
+            }
+        } else
         for (int k = tid; k < nseams; k += PV_THREADS) {
             const long long seam = (2LL * k + 1) * half;
             if (coop) rec_s[k] = -1;
@@ -939,19 +980,19 @@ int launch_pav_tree(int loss, int64_t n, double rho, const double* ms, const dou
                     hipStream_t s, const double* u0a, const double* u0b) {
     RBL_HIP(hipMemsetAsync(merge_counter, 0, sizeof(u32), s));
     if (n <= 0) return RBL_OK;
+    static const bool thread_seams = [] {
+        const char* e = getenv("RBL_PAV_THREAD_SEAMS");   // one thread per seam everywhere, for comparison
+        return e && e[0] == '1';
+    }();
     // levels 0 .. log2(PB_TILE): prox + in-LDS merges, one tile per workgroup
     const unsigned tiles = (unsigned)((n + PB_TILE - 1) / PB_TILE);
     if (loss == RBL_LOSS_BCE)
         hipLaunchKernelGGL(k_pav_bottom<0>, dim3(tiles), dim3(PV_THREADS), 0, s, ms, sa, sb, branch, rho, (long long)n, u,
-                           merge_counter, u0a, u0b);
+                           merge_counter, u0a, u0b, thread_seams ? 0 : 1);
     else
         hipLaunchKernelGGL(k_pav_bottom<1>, dim3(tiles), dim3(PV_THREADS), 0, s, ms, sa, sb, branch, rho, (long long)n, u,
-                           merge_counter, u0a, u0b);
+                           merge_counter, u0a, u0b, thread_seams ? 0 : 1);
     // upper levels: one WAVE per seam (64-ary inner searches), pooled ranges written by a fill pass
-    static const bool thread_seams = [] {
-        const char* e = getenv("RBL_PAV_THREAD_SEAMS");   // the one-thread-per-seam kernel, for comparison
-        return e && e[0] == '1';
-    }();
     int level = PB_TILE_LOG + 1;
     for (long long half = PB_TILE; half < n; half <<= 1, ++level) {
         const long long nseams = (n + 2 * half - 1) / (2 * half);

@@ -105,6 +105,38 @@ def test_pav_vs_oracle(L):
                 assert np.max(np.abs(u - ref)) <= 1e-10 * max(1.0, np.max(np.abs(ref))), (fam, loss, rho, n)
 
 
+def test_pav_wave_search_regression(L):
+    """Inputs captured from iteration 19 of a superquantile solve (n = 1500): the wave-cooperative
+    64-ary search once returned lo - 1 when exactly 64 positions were left and none satisfied the
+    predicate, which pooled 3 positions too many at the top of the tile.  Expected values: the
+    oracle's exact PAV on the same inputs."""
+    g = load_golden("g10_pav_wave_search_regression.npz")
+    u, _ = L.k_pav("binary_cross_entropy", g["sigma"], float(g["rho"]), g["m"])
+    assert np.max(np.abs(u - g["u"])) <= 1e-12
+
+
+def test_pav_many_sizes_vs_oracle(L):
+    """many (n, family, rho) combinations - partial tiles, sizes around multiples of 64 and of the
+    2048-position tile, several upper levels - against the oracle's exact PAV"""
+    from oracle import pav, weights
+    rng = np.random.default_rng(11)
+    sizes = [65, 127, 128, 129, 1023, 1025, 1088, 1500, 1984, 2047, 2048, 2049, 2112, 4097, 6200, 8191, 8256, 20000, 70001]
+    fams = FAMILIES + [("ehrm", None)]
+    for n in sizes:
+        for rep in range(3):
+            fam, args = fams[int(rng.integers(len(fams)))]
+            loss = ("binary_cross_entropy", "hinge")[int(rng.integers(2))]
+            rho = float(10.0 ** rng.uniform(-6.5, 0.5))
+            sa, sb = weights.get_weights(fam, n, args)
+            sg = sb if rep % 2 else sa
+            m = np.sort(rng.standard_normal(n) * float(10.0 ** rng.uniform(-1, 1)) + rng.uniform(-2, 2))
+            if rep == 2:
+                m = np.round(m, 2)          # many ties
+            u, _ = L.k_pav(loss, sg, rho, m)
+            ref, _ = pav.pav_exact(loss, sg, rho, m)
+            assert np.max(np.abs(u - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref))), (n, fam, loss, rho, rep)
+
+
 def test_pav_golden_g2(L):
     g = load_golden("g2_pav.npz")
     tight = 0
