@@ -411,6 +411,10 @@ def test_single_sweep_paths(loss, reg_kind):
     (901, 333, "f32", "binary_cross_entropy", "l1_reg"),     # d not a multiple of 4 (padded columns), 2 passes
     (645, 1001, "f32", "hinge", "l2_reg"),                   # d = 1001 (the AoRR driver's intercept column), 4 passes
     (1203, 131, "f64", "binary_cross_entropy", "l2_reg"),    # 2 passes in fp64, odd everything
+    (5, 1100, "f32", "binary_cross_entropy", "l2_reg"),      # fewer rows than one super-batch, wide rows
+    (17, 2300, "f64", "hinge", "l2_reg"),                    # one full super-batch + 1 row
+    (3, 260, "f32", "binary_cross_entropy", "l1_reg"),       # 3 rows, wave-per-row kernel
+    (33, 520, "f64", "binary_cross_entropy", "l2_reg"),      # 2 super-batches + 1 row
 ])
 def test_single_sweep_wide_rows(rows, cols, storage, loss, reg_kind):
     """The single-sweep path for every row width (sweep_erm.hip: wave-per-row up to 4 / 8 passes,
