@@ -198,11 +198,17 @@ class ShardedADMM:
     NS = 64      # regular samples per rank for the splitters
     K = 63       # seam-search candidates per rank and round (64-ary search: 5 rounds decide 16M positions)
 
-    def __init__(self, engine, group=None, dist_z=True):
+    def __init__(self, engine, group=None, dist_z=True, world=None, rank=None):
+        """world / rank: only for drivers that bring their own collectives by overriding _allreduce,
+        _allgather_rows, _gather_small, _gather_counts and _alltoall (tests/test_gpu_dist.py runs 8
+        ranks as threads of one process that way); otherwise they come from torch.distributed."""
         self.e = engine
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if world is not None:
+            self.world, self.rank = int(world), int(rank)
+        else:
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         _, _, self.nmax = shard_rows(engine.n_total, self.world, self.rank)
         self._gather = None
         self.dist_z = bool(dist_z) and hasattr(engine, "zd_sort_local")

@@ -115,3 +115,130 @@ def test_rccl_accepts_the_library_views_one_rank():
                          timeout=600, env=dict(os.environ, MASTER_PORT=str(29700 + os.getpid() % 200)))
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     assert out.stdout.strip().splitlines()[-1] == "OK"
+
+
+
+# ---------------------------------------------------------------------------------------------
+# 8 ranks as THREADS of one process (the box allows 6 GPU processes and RCCL one rank per device,
+# so this is the only way to run the 8-rank protocol on the device path here): each thread owns
+# a librbl handle for its row shard; the collectives are a barrier-based hub on device tensors.
+class _Hub:
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slot = [None] * world
+        self.total = None
+
+
+def _make_thread_driver(ShardedADMM, hub):
+    import torch
+
+    class ThreadSharded(ShardedADMM):
+        def _exchange(self, item):
+            hub.slot[self.rank] = item
+            hub.bar.wait()
+            items = list(hub.slot)
+            hub.bar.wait()
+            return items
+
+        def _allreduce(self, t):
+            if t.numel() == 0:
+                return
+            items = self._exchange(t)
+            if self.rank == 0:
+                tot = items[0].clone()
+                for x in items[1:]:
+                    tot += x               # fixed order: every rank gets the same bits
+                hub.total = tot
+            hub.bar.wait()
+            t.copy_(hub.total)
+            torch.cuda.synchronize()
+            hub.bar.wait()
+
+        def _gather_small(self, t):
+            out = torch.cat([x.reshape(-1) for x in self._exchange(t.clone())])
+            torch.cuda.synchronize()
+            hub.bar.wait()
+            return out
+
+        def _gather_counts(self, counts):
+            return np.array(self._exchange(list(counts)), dtype=np.int64).reshape(self.world, self.world)
+
+        def _alltoall(self, send, send_counts, recv, recv_counts):
+            items = self._exchange((send, [int(c) for c in send_counts]))
+            pos = 0
+            for src, (buf, cnts) in enumerate(items):
+                off = sum(cnts[: self.rank])
+                c = cnts[self.rank]
+                assert c == int(recv_counts[src])
+                recv[pos:pos + c].copy_(buf[off:off + c])
+                pos += c
+            torch.cuda.synchronize()
+            hub.bar.wait()              # nobody overwrites a send buffer that is still being read
+
+        def _allgather_rows(self, local):
+            return torch.cat([x.reshape(-1) for x in self._exchange(local.clone())])
+
+    return ThreadSharded
+
+
+def _thread_rank(rank, world, cfg, hub, out, errs):
+    try:
+        import torch
+        import admm_for_rank_based_loss_amd as rbl
+        from admm_for_rank_based_loss_amd.dist import ShardedADMM, GpuEngine, shard_rows
+        torch.cuda.set_device(0)
+        lo, cnt, _ = shard_rows(cfg["n"], world, rank)
+        s = rbl.Solver(cnt, cfg["d"], cfg["wf"], cfg["loss"], reg=cfg["reg"], wstep=cfg["wstep"], B=cfg.get("B"),
+                       args=cfg.get("args"), n_total=cfg["n"], row_offset=lo, tol=0.0, storage="f64")
+        drv = _make_thread_driver(ShardedADMM, hub)(GpuEngine(s, 0), world=world, rank=rank)
+        drv.setup_synthetic(seed=11)
+        drv.setup_gram()
+        hist = []
+        for _ in range(cfg["iters"]):
+            st = drv.step(True)
+            hist.append((st.primal, st.dual, st.rho, st.objective))
+        state = s.get_state()
+        out[rank] = dict(w=state["w"], z=state["z"], hist=np.array(hist))
+    except BaseException as e:       # a dead thread must not leave the others in a barrier forever
+        errs.append((rank, repr(e)))
+        hub.bar.abort()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n=50003, d=33, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=6),
+    dict(n=40000, d=21, wf="ehrm", B=-5.0, loss="binary_cross_entropy", reg=0.01, wstep=2, iters=5),
+    dict(n=30011, d=21, wf="aorr", args=[0.2, 0.8], loss="hinge", reg=1e-4, wstep=2, iters=6),
+    dict(n=40000, d=48, wf="erm", loss="binary_cross_entropy", reg=0.01, wstep=1, iters=8),
+], ids=["superq", "ehrm", "aorr_hinge", "erm"])
+def test_eight_ranks_as_threads_match_single_handle(cfg, tmp_path):
+    """the 8-rank protocol (three levels of the merge tree over ranks, all-to-all exchanges, the
+    single-collective erm iteration) on the device path against the single-handle run"""
+    import threading
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import torch  # noqa: F401  (imports finish in this thread before the rank threads start)
+    import admm_for_rank_based_loss_amd as rbl
+    from admm_for_rank_based_loss_amd import dist as _d  # noqa: F401
+    rbl._lib.load()
+    world = 8
+    out1 = str(tmp_path / "w1_r%d.npz")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_run, args=(0, 1, 29999, cfg, out1))
+    p.start(); p.join(300)
+    assert p.exitcode == 0
+    one = np.load(out1 % 0)
+    hub, out, errs = _Hub(world), [None] * world, []
+    ts = [threading.Thread(target=_thread_rank, args=(r, world, cfg, hub, out, errs)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(600)
+    assert not errs, errs
+    for r in out[1:]:
+        assert np.array_equal(out[0]["w"], r["w"]) and np.array_equal(out[0]["hist"], r["hist"])
+    z8 = np.concatenate([r["z"] for r in out])
+    assert np.max(np.abs(out[0]["w"] - one["w"])) <= 1e-9 * max(1.0, np.max(np.abs(one["w"])))
+    assert np.max(np.abs(z8 - one["z"])) <= 1e-8 * max(1.0, np.max(np.abs(one["z"])))
+    assert np.allclose(out[0]["hist"], one["hist"], rtol=1e-8, atol=1e-12)
