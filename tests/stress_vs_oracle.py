@@ -1,7 +1,9 @@
 """Randomized whole-solver parity run (TEST INFRASTRUCTURE, not collected by pytest): random
 family / loss / regulariser / shape, 12 ADMM iterations on the GPU against the oracle's exact mode.
     python tests/stress_vs_oracle.py SEED TRIALS [MAX_ROWS]
-Round 1: 660 trials (seeds 1-5 and 7, rows up to 80 000), worst relative deviation 8e-14."""
+Round 1: 660 fp64 trials (seeds 1-5 and 7, rows up to 80 000), worst relative deviation 8e-14; 450
+more with 40 % fp32 storage and rows up to 2600 wide (seeds 11-13): fp64 as before, fp32 within 2e-4
+(EHRM, non-convex: 7e-4)."""
 import os
 import sys
 import time
@@ -23,6 +25,10 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     if fam == "erm" and rng.random() < 0.5:
         d = int(rng.integers(140, 400))          # single-sweep kernel territory (fp64: PK > 32)
         n = int(rng.integers(200, 3000))
+        if rng.random() < 0.3:
+            d = int(rng.integers(1030, 2600))    # workgroup-per-row kernel
+            n = int(rng.integers(20, 600))
+    storage = "f32" if rng.random() < 0.4 else "f64"
     kw = dict(weight_function=fam, loss=loss, args=args)
     if fam == "ehrm": kw["B"] = -5
     if fam == "aorr_dc": kw["args"] = [min(80, n // 3), 3]
@@ -32,7 +38,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     nit = 12
     try:
         ref = admm.admm_solve(X, y, max_iter=nit, mode="exact", tol=0.0, **kw)
-        s = R.ADMMmethod(X, y, max_iter=nit, tol=0.0, storage="f64", **kw)
+        s = R.ADMMmethod(X, y, max_iter=nit, tol=0.0, storage=storage, **kw)
         worst = 0.0
         for i in range(nit):
             st = s._s.step(want_objective=True)
@@ -40,9 +46,12 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
         w = s._s.get_state()["w"]
         werr = np.max(np.abs(w - ref.w)) / max(1.0, np.max(np.abs(ref.w)))
         tol = 1e-8 if loss == "binary_cross_entropy" else 1e-6
+        if storage == "f32":
+            # D rounded to fp32 is a perturbed problem; the non-convex families amplify the perturbation
+            tol = 5e-2 if fam in ("aorr", "aorr_dc") else (5e-3 if fam == "ehrm" else 2e-4)
         flag = "" if (worst <= tol and werr <= tol) else "  <<<<<< MISMATCH"
         if flag: bad += 1
-        print(f"{trial:3d} {fam:13s} {loss[:5]} n={n:5d} d={d:3d} {regk}={kw[regk]:.1e} primal_err={worst:.1e} w_err={werr:.1e}{flag}", flush=True)
+        print(f"{trial:3d} {fam:13s} {loss[:5]} {storage} n={n:5d} d={d:4d} {regk}={kw[regk]:.1e} primal_err={worst:.1e} w_err={werr:.1e}{flag}", flush=True)
     except Exception as e:
         print(trial, fam, loss, n, d, "EXC", repr(e)[:200], flush=True); bad += 1
 print("bad =", bad, "time", round(time.time() - t0, 1))
