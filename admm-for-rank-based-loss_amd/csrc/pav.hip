@@ -563,12 +563,19 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_seam_wave(double* __restrict
     }
 }
 
-__global__ void k_pav_fill(double* __restrict__ u, long long n, int level_shift, const SeamRec* __restrict__ recs) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x) {
-        const SeamRec r = recs[i >> level_shift];
-        if (r.s >= 0 && i >= r.s && i <= r.e) u[i] = r.x;
-    }
+// One block per 4096 positions: it looks at the record of the seam its positions belong to and
+// returns at once unless the pooled range reaches into them (most blocks of most levels).
+constexpr int PF_CHUNK = 4096;
+__global__ __launch_bounds__(256) void k_pav_fill(double* __restrict__ u, long long n, int level_shift,
+                                                   const SeamRec* __restrict__ recs) {
+    const long long b0 = (long long)blockIdx.x * PF_CHUNK;
+    if (b0 >= n) return;
+    const SeamRec r = recs[b0 >> level_shift];   // level_shift >= 12: a chunk never straddles two segments
+    if (r.s < 0) return;
+    long long lo = b0 > r.s ? b0 : r.s, hi = b0 + PF_CHUNK - 1;
+    if (hi > r.e) hi = r.e;
+    if (hi >= n) hi = n - 1;
+    for (long long i = lo + threadIdx.x; i <= hi; i += 256) u[i] = r.x;
 }
 
 // ---------------------------------------------------------------- setup kernels
@@ -1013,7 +1020,8 @@ int launch_pav_tree(int loss, int64_t n, double rho, const double* ms, const dou
                 hipLaunchKernelGGL(k_pav_seam_wave<1>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, half, pa, pb,
                                    pm, branch, rho, recs, nseams, merge_counter);
         }
-        hipLaunchKernelGGL(k_pav_fill, dim3(pv_grid(n)), dim3(256), 0, s, u, (long long)n, level, recs);
+        hipLaunchKernelGGL(k_pav_fill, dim3((unsigned)((n + PF_CHUNK - 1) / PF_CHUNK)), dim3(256), 0, s, u, (long long)n, level,
+                           recs);
     }
     RBL_HIP(hipGetLastError());
     return RBL_OK;
