@@ -953,13 +953,16 @@ int rbl_phase_w(rbl_solver* h) {
     // status, so the device works through them while the host waits.  Only when the kernel did
     // not converge (FISTA then changes w again) are they enqueued a second time.
     bool fs_pending = spec;
+    const bool predict = h->fused_ok && h->p_valid;
+    // the active-set lasso kernel leaves G w of its solution in ww.Gy (it needs the gradient for its
+    // own optimality test): no d x d product for the rho prediction unless FISTA had to take over
+    bool gw_ready = predict && wstep == RBL_WSTEP_L1;
     if (!spec)
         RBL_TRY(run_wstep(wstep, h->G, h->ld, h->q, h->step_rho, h->cfg.reg, h->smooth_t, h->L, h->cfg.w_tol, 100000,
-                          h->w, h->ww, &h->inner_iters, h->stream, &fs_pending, nullptr, h->w_prev));
-    const bool predict = h->fused_ok && h->p_valid;
+                          h->w, h->ww, &h->inner_iters, h->stream, &fs_pending, nullptr, h->w_prev, gw_ready));
     auto after_w = [&]() -> int {
         if (predict) {
-            RBL_TRY(launch_symv(h->G, h->ld, h->w, h->ww.Gy, h->stream));
+            if (!gw_ready) RBL_TRY(launch_symv(h->G, h->ld, h->w, h->ww.Gy, h->stream));
             RBL_TRY(launch_predict_rho(h->ld, h->q, h->p, h->p_alt, h->w, h->w_prev, h->ww.Gy, q_zz(h), h->step_rho,
                                        217.0 * (double)h->d, h->pred, h->red2, h->stream));
         } else {
@@ -972,7 +975,10 @@ int rbl_phase_w(rbl_solver* h) {
         bool fell_back = false;
         RBL_TRY(finish_wstep_l1(h->G, h->ld, h->q, h->step_rho, h->cfg.reg, h->L, h->cfg.w_tol, 100000, h->w, h->ww,
                                 &h->inner_iters, h->stream, &fell_back));
-        if (fell_back) RBL_TRY(after_w());
+        if (fell_back) {
+            gw_ready = false;
+            RBL_TRY(after_w());
+        }
     }
     h->pred_valid = false;
     if (predict) {
@@ -1082,8 +1088,7 @@ int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
         if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev_spec[0], h->stream));
         bool fs_pending = false;
         RBL_TRY(run_wstep(RBL_WSTEP_L1, h->G, h->ld, h->q, 1.0, h->cfg.reg, h->smooth_t, h->L, h->cfg.w_tol, 100000, h->w,
-                          h->ww, nullptr, h->stream, &fs_pending, h->pred, h->w_prev));
-        RBL_TRY(launch_symv(h->G, h->ld, h->w, h->ww.Gy, h->stream));
+                          h->ww, nullptr, h->stream, &fs_pending, h->pred, h->w_prev, true));   // leaves G w in ww.Gy
         RBL_TRY(launch_predict_rho(h->ld, h->q, h->p, h->p_alt, h->w, h->w_prev, h->ww.Gy, q_zz(h), 0.0,
                                    217.0 * (double)h->d, h->pred, h->red2, h->stream, h->pred));
         if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev_spec[1], h->stream));

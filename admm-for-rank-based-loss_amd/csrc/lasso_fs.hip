@@ -100,7 +100,8 @@ __device__ inline void chol_solve(FsShared& S, int na, double* b, double* xo) {
 __global__ __launch_bounds__(FS_THREADS) void k_lasso_fs(const double* __restrict__ G, long long ld, long long d,
                                                           const double* __restrict__ q, double* __restrict__ w,
                                                           double kappa_val, const double* __restrict__ rho_dev,
-                                                          double reg, double* __restrict__ w_prev_out, int max_steps,
+                                                          double reg, double* __restrict__ w_prev_out,
+                                                          double* __restrict__ Gw_out, int max_steps,
                                                           int* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char fs_raw[];
     FsShared& S = *reinterpret_cast<FsShared*>(fs_raw);
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_lasso_fs(const double* __restric
                 if (S.active[i]) continue;
                 double g = -q[i];
                 for (int a = 0; a < na; ++a) g = __builtin_fma(G[(long long)S.A[a] * ld + i], S.wA[a], g);
+                if (Gw_out) Gw_out[i] = g + q[i];   // (G w)_i: final once this test lets the loop end
                 const double ag = fabs(g);
                 if (ag > best) {  // ascending i: keeps the smallest index among equals
                     best = ag;
@@ -334,6 +336,16 @@ __global__ __launch_bounds__(FS_THREADS) void k_lasso_fs(const double* __restric
     }
     __syncthreads();
     for (int a = tid; a < na; a += FS_THREADS) w[S.A[a]] = S.wA[a];
+    // G w of the solution for the caller's rho prediction (saves a d x d product): the inactive
+    // coordinates were written by the last activation test, the active ones are added here
+    if (Gw_out && status == 0) {
+        for (int a = tid; a < na; a += FS_THREADS) {
+            double g = 0.0;
+            for (int b = 0; b < na; ++b) g = __builtin_fma(G[(long long)S.A[a] * ld + S.A[b]], S.wA[b], g);
+            Gw_out[S.A[a]] = g;
+        }
+        for (long long j = nd + tid; j < ld; j += FS_THREADS) Gw_out[j] = 0.0;   // padding columns
+    }
     if (tid == 0) {
         out[1] = outer;
         out[2] = steps;
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(FS_THREADS) void k_lasso_fs(const double* __restric
 
 
 int launch_lasso_fs(const double* G, int64_t ld, int64_t d, const double* q, double* w, double kappa, int* out_dev,
-                    hipStream_t s, const double* rho_dev, double reg, double* w_prev_out) {
+                    hipStream_t s, const double* rho_dev, double reg, double* w_prev_out, double* Gw_out) {
     if (d > FS_MAXD) {
         rbl_set_error("lasso_fs: d too large");
         return RBL_ERR_INVALID;
@@ -359,7 +371,7 @@ int launch_lasso_fs(const double* G, int64_t ld, int64_t d, const double* q, dou
         attr_set = true;
     }
     hipLaunchKernelGGL(k_lasso_fs, dim3(1), dim3(FS_THREADS), sizeof(FsShared), s, G, (long long)ld, (long long)d, q, w,
-                       kappa, rho_dev, reg, w_prev_out, 6 * FS_MAX + 64, out_dev);
+                       kappa, rho_dev, reg, w_prev_out, Gw_out, 6 * FS_MAX + 64, out_dev);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

@@ -191,14 +191,15 @@ int launch_power_iteration(const double* G, int64_t d, double* tmp1, double* tmp
 int run_wstep(int wstep, const double* G, int64_t d, const double* q, double rho, double reg, double smooth_t,
               double L, double tol, int max_inner, double* w, WstepWorkspace& ws, int* iters_host,
               hipStream_t s, bool* fs_pending = nullptr, const double* rho_dev = nullptr,
-              double* w_prev_out = nullptr);
+              double* w_prev_out = nullptr, bool want_Gw = false);   // want_Gw: the lasso kernel leaves G w in ws.Gy
 int finish_wstep_l1(const double* G, int64_t d, const double* q, double rho, double reg, double L, double tol,
                     int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s, bool* fell_back);
 int launch_w_stats(int64_t d, const double* w, const double* w_prev, double* out3, hipStream_t s);
 // lasso_fs.hip: exact active-set (feature-sign) lasso in one workgroup; out_dev = 4 ints
 // rho_dev != NULL: kappa = reg / (2 rho_dev[0]) is formed on the device; w_prev_out != NULL: the warm start is saved there
 int launch_lasso_fs(const double* G, int64_t ld, int64_t d, const double* q, double* w, double kappa, int* out_dev,
-                    hipStream_t s, const double* rho_dev = nullptr, double reg = 0.0, double* w_prev_out = nullptr);
+                    hipStream_t s, const double* rho_dev = nullptr, double reg = 0.0, double* w_prev_out = nullptr,
+                    double* Gw_out = nullptr);   // Gw_out: G w of the solution (valid when the status is 0)
 int launch_reg_terms(int64_t d, const double* w, double* out2 /* [sum w^2, sum |w|] */, hipStream_t s);
 int launch_soft_threshold(int64_t d, double* w, double t, hipStream_t s);
 

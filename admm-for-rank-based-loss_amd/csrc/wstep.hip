@@ -363,7 +363,7 @@ int run_fista(int mode, const double* G, int64_t ld, const double* q, double rho
 
 int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rho, double reg, double smooth_t,
               double L, double tol, int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s,
-              bool* fs_pending, const double* rho_dev, double* w_prev_out) {
+              bool* fs_pending, const double* rho_dev, double* w_prev_out, bool want_Gw) {
     if (fs_pending) *fs_pending = false;
     if (ld > (long long)UPD_THREADS * UPD_PER) {
         rbl_set_error("w-step: d=%lld exceeds the single-block update limit %d", (long long)ld, UPD_THREADS * UPD_PER);
@@ -407,7 +407,8 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
         // its capacity (e.g. the dense initial w of algorithms.py:42) or it hits its cap.  The
         // kernel writes its status block straight into pinned host memory.
         ws.pin[0] = -1;   // sentinel: the kernel stores its status (>= 0) here last
-        RBL_TRY(launch_lasso_fs(G, ld, ld, q, w, reg / (2.0 * rho), ws.pin, s, rho_dev, reg, w_prev_out));
+        RBL_TRY(launch_lasso_fs(G, ld, ld, q, w, reg / (2.0 * rho), ws.pin, s, rho_dev, reg, w_prev_out,
+                                want_Gw ? ws.Gy : nullptr));
         if (fs_pending) {
             *fs_pending = true;
             return RBL_OK;
