@@ -243,3 +243,63 @@ def test_weight_errors():
         weights.get_weights("nope", 10, [1])
     with pytest.raises(ValueError, match="need args"):
         weights.get_weights("aorr_dc", 10, [2, 5])
+
+
+def test_zdist_rank_tree_and_rounds():
+    """oracle/zdist.py: the merge tree over ranks pairs every rank exactly once per level where it
+    has a partner, the round count decides every position, and a single-process simulation of the
+    distributed z-step (P chunks, K-ary seam search on summaries) equals the exact PAV."""
+    from oracle import zdist, pav, weights
+    for world in (1, 2, 3, 5, 8, 13):
+        for level in range(1, zdist.num_levels(world) + 1):
+            seen = {}
+            for r in range(world):
+                info = zdist.seam_of(r, world, level)
+                if info is None:
+                    continue
+                k, side, a0, b0, b1 = info
+                assert a0 <= r < b1 and (side == 0) == (r < b0)
+                seen.setdefault(k, set()).add(r)
+            for k, rs in seen.items():
+                assert rs == set(range(min(rs), max(rs) + 1))      # a seam's ranks are contiguous
+    for K in (1, 3, 15, 63):
+        for n in (0, 1, K, K + 1, 1000, 10 ** 6):
+            s, r = n, 0
+            while s > 0:                      # what a round leaves undecided in the worst case
+                s = 0 if s <= K else s // (K + 1)
+                r += 1
+            assert zdist.num_rounds(n, K) >= r
+    rng = np.random.default_rng(5)
+    for trial in range(30):
+        n, P, K = int(rng.integers(1, 3000)), int(rng.choice([2, 3, 4, 7, 8])), int(rng.choice([2, 5, 15, 63]))
+        loss = ("binary_cross_entropy", "hinge")[trial % 2]
+        fam, args = (("superquantile", [0.5]), ("extremile", [2.0]), ("aorr", [0.2, 0.8]), ("esrm", [1.0]))[trial % 4]
+        sigma, _ = weights.get_weights(fam, n, args)
+        rho = float(10.0 ** rng.uniform(-6, 0))
+        m = np.sort(rng.standard_normal(n) * 2)
+        if trial % 5 == 0:
+            m = np.round(m, 1)
+        cuts = np.sort(rng.integers(0, n + 1, size=P - 1))           # uneven chunks, some possibly empty
+        b = np.concatenate([[0], cuts, [n]])
+        chunks = [zdist.RankChunk(loss, rho, m[b[r]:b[r + 1]], sigma[b[r]:b[r + 1]]) for r in range(P)]
+        rounds = zdist.num_rounds(max(c.n for c in chunks), K)
+        for level in range(1, zdist.num_levels(P) + 1):
+            bounds = np.array([c.bounds() for c in chunks])
+            for r, c in enumerate(chunks):
+                c.seam_setup(r, P, level, bounds)
+            cand = part = None
+            for _ in range(rounds):
+                if part is not None:
+                    for c in chunks:
+                        c.update(cand, part, K, P, level)
+                cand = np.concatenate([c.propose(K) for c in chunks])
+                part = sum(c.evaluate(cand, K, P, level) for c in chunks)
+            for c in chunks:
+                c.update(cand, part, K, P, level)
+            nseams = (P + 1) // 2
+            tot = sum(c.pooled_sums(nseams) for c in chunks)
+            for c in chunks:
+                c.fill(tot)
+        u = np.concatenate([c.u for c in chunks])
+        ref = pav.pav_exact(loss, sigma, rho, m)[0] if n else np.zeros(0)
+        assert np.max(np.abs(u - ref), initial=0.0) <= 1e-10 * max(1.0, np.max(np.abs(ref), initial=0.0)), (trial, n, P, K)
