@@ -110,6 +110,7 @@ SIGNATURES = {
     "rbl_kernel_time": (C.c_int, [_P, C.c_int, _D, _I64]),
     "rbl_reset_kernel_times": (C.c_int, [_P]),
     "rbl_profile_kernels": (C.c_int, [_P, C.c_int]),
+    "rbl_profile_sampling": (C.c_int, [_P, C.c_int]),
     "rbl_k_prox": (C.c_int, [C.c_int, C.c_int64, _P, C.c_double, _P, _P]),
     "rbl_k_sort": (C.c_int, [C.c_int64, _P, _P, _P]),
     "rbl_k_pav": (C.c_int, [C.c_int, C.c_int64, _P, C.c_double, _P, _P, _I64]),

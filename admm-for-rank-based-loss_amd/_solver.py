@@ -315,6 +315,10 @@ class Solver:
         (kernel_time()); 2: also around the phases (the ms_* fields of the step statistics)."""
         _lib.check(self.lib.rbl_profile_kernels(self._h, int(enable)))
 
+    def profile_sampling(self, every=1):
+        """kernel events on every `every`-th iteration only (include/rbl.h: rbl_profile_sampling)."""
+        _lib.check(self.lib.rbl_profile_sampling(self._h, int(every)))
+
     def reset_kernel_times(self):
         _lib.check(self.lib.rbl_reset_kernel_times(self._h))
 

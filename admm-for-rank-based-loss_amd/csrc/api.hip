@@ -68,6 +68,7 @@ struct rbl_solver {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t kev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // gemv, gemvt, sweep_erm: begin/end
     bool profile = false, kev_pending[3] = {false, false, false};
+    int profile_every = 1;   // kernel events on every profile_every-th iteration (rbl_profile_sampling)
     double kt_ms[3] = {0.0, 0.0, 0.0};
     int64_t kt_n[3] = {0, 0, 0};
 
@@ -879,6 +880,9 @@ static int require_ready(rbl_solver* h) {
 static inline double* q_pinit(rbl_solver* h) { return h->q + h->ld; }      // D^T lambda (first pass only)
 static inline double* q_zz(rbl_solver* h) { return h->q + 2 * h->ld; }     // ||z||^2 of the current z
 
+// kernel events in this iteration?  (every profile_every-th one: an event record costs ~5 us of stream time)
+static inline bool prof_now(const rbl_solver* h) { return h->profile && (h->iter % h->profile_every) == 0; }
+
 int rbl_phase_m(rbl_solver* h) {
     RBL_ENTER_ITER(h);
     RBL_TRY(require_ready(h));
@@ -916,14 +920,14 @@ int rbl_phase_z(rbl_solver* h, const void* m_all_dev) {
 int rbl_phase_q(rbl_solver* h) {
     RBL_ENTER_ITER(h);
     if (!(h->fused_ok && h->z_ready)) {
-        if (h->profile) RBL_HIP(hipEventRecord(h->kev[2], h->stream));
+        if (prof_now(h)) RBL_HIP(hipEventRecord(h->kev[2], h->stream));
         // rank-weighted problems: the z-step's scatter writes z alone (one random access per row); c = z +
         // lambda/rho (algorithms.py:192) is a streaming pass here.  (Forming it inside the sweep was tried:
         // the per-row division on the sweep's critical path costs 0.9 ms, the streaming pass 30 us.)
         if (h->sorted_path) RBL_TRY(launch_make_c(h->n, h->z, h->lam, h->step_rho, h->c, h->stream));
         RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream,
-                             h->profile ? h->kev[3] : nullptr));
-        if (h->profile) h->kev_pending[1] = h->n > 0;
+                             prof_now(h) ? h->kev[3] : nullptr));
+        if (prof_now(h)) h->kev_pending[1] = h->n > 0;
         if (h->fused_ok && !h->p_valid) {
             // D^T lambda seeds the d-space recurrence used to predict the primal residual
             RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->lam, h->slab, q_pinit(h), h->num_cu, h->stream));
@@ -1005,26 +1009,26 @@ int rbl_phase_dual(rbl_solver* h, int want_objective) {
 
     h->fused_ran = false;
     if (h->fused_ok && h->pred_valid) {
-        if (h->profile) RBL_HIP(hipEventRecord(h->kev[4], h->stream));
+        if (prof_now(h)) RBL_HIP(hipEventRecord(h->kev[4], h->stream));
         RBL_TRY(launch_sweep_erm(h->storage, h->cfg.loss, h->D, h->n, h->ld, h->w, h->z, h->lam, h->v, h->z_next,
                                  h->sigma0, h->step_rho, h->pred, h->slab, h->partials, h->q, h->red, q_zz(h),
-                                 h->num_cu, h->stream, h->profile ? h->kev[5] : nullptr, want_objective));
-        if (h->profile) h->kev_pending[2] = h->n > 0;
+                                 h->num_cu, h->stream, prof_now(h) ? h->kev[5] : nullptr, want_objective));
+        if (prof_now(h)) h->kev_pending[2] = h->n > 0;
         h->fused_ran = true;
         h->v_valid = want_objective != 0;   // without objective logging the pass does not store v (ensure_v recomputes it if a misprediction asks)
         if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[4], h->stream));
     } else if (h->fuse_v) {
         // v = D w and the lambda update in one pass (timed as the gemv of the iteration)
-        if (h->profile) RBL_HIP(hipEventRecord(h->kev[0], h->stream));
+        if (prof_now(h)) RBL_HIP(hipEventRecord(h->kev[0], h->stream));
         RBL_TRY(launch_sweep_v(h->storage, h->D, h->n, h->ld, h->w, h->z, h->lam, h->v, h->step_rho, h->partials, h->red,
-                               h->num_cu, h->stream, h->profile ? h->kev[1] : nullptr));
-        if (h->profile) h->kev_pending[0] = h->n > 0;
+                               h->num_cu, h->stream, prof_now(h) ? h->kev[1] : nullptr));
+        if (prof_now(h)) h->kev_pending[0] = h->n > 0;
         h->v_valid = true;
         if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[4], h->stream));
     } else {
-        if (h->profile) RBL_HIP(hipEventRecord(h->kev[0], h->stream));
+        if (prof_now(h)) RBL_HIP(hipEventRecord(h->kev[0], h->stream));
         RBL_TRY(launch_gemv(h->storage, h->D, h->n, h->ld, h->w, h->v, h->num_cu, h->stream));
-        if (h->profile) {
+        if (prof_now(h)) {
             RBL_HIP(hipEventRecord(h->kev[1], h->stream));
             h->kev_pending[0] = true;
         }
@@ -1592,6 +1596,16 @@ int rbl_profile_kernels(rbl_solver* h, int enable) {
 
 // SPD, DI, EOD, AOD, TI, FNRD of the linear classifier on this handle's rows
 // (src/util/fair_metric.py:3-41); group: n doubles with values 0 / 1
+int rbl_profile_sampling(rbl_solver* h, int every) {
+    RBL_ENTER(h);
+    if (every < 1) {
+        rbl_set_error("profile_sampling: every must be >= 1");
+        return RBL_ERR_INVALID;
+    }
+    h->profile_every = every;
+    return RBL_OK;
+}
+
 int rbl_fair_statistics(rbl_solver* h, const double* w, const double* group, double threshold, double* out6) {
     RBL_ENTER(h);
     if (!h->data_ready || !w || !group || !out6) {

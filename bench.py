@@ -176,6 +176,10 @@ def main():
     for _ in range(a.warmup):
         step()
     s.profile_kernels(2 if a.phase_times else 1)
+    # the roofline timing brackets every 4th launch of the sweep kernels with HIP events (every launch in
+    # short runs): two event records cost ~11 us of stream time, 2 % of a rank's pass at 8 GPUs
+    prof_every = 4 if a.steps >= 16 else 1
+    s.profile_sampling(prof_every)
     s.reset_kernel_times()
     torch.cuda.synchronize()
     if world > 1:
@@ -228,7 +232,7 @@ def main():
                        "single_sweep_iterations": n_fused, "rho_mispredictions": n_mispred},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_" + dom,
-                         "bytes_per_launch": bytes_per_launch,
+                         "bytes_per_launch": bytes_per_launch, "timed_every": prof_every,
                          "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"],
                                          "GBps": round(bytes_per_launch / (v["avg_ms"] * 1e-3) / 1e9, 1)
                                          if v["avg_ms"] > 0 else 0.0} for k, v in kt.items()}},

@@ -242,6 +242,9 @@ int  rbl_reset_kernel_times(rbl_solver* h);
  * time), 1 = events around the sweep kernels (rbl_kernel_time), 2 = also around the phases (the
  * ms_* fields of rbl_stats, 0 otherwise) */
 int  rbl_profile_kernels(rbl_solver* h, int enable);
+/* kernel events (level >= 1) on every `every`-th iteration only; default 1.  With several GPUs the pass
+ * of a rank is short (0.55 ms at 8 x 750 000 rows) and two events per iteration are 2 % of it. */
+int  rbl_profile_sampling(rbl_solver* h, int every);
 
 /* ---- kernel-level entry points over host buffers (parity tests call these) -------- */
 /* element prox (src/util/individual_solver.py:112-123) */
