@@ -34,3 +34,10 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVES SQ_
     --kernel-trace --output-format csv -d "$OUT/pmc_lds" -o l -- python3 $B --config C2sq --steps 5 > "$OUT/l.log" 2>&1
 python3 tools/lds_from_pmc.py "$(find "$OUT/pmc_lds" -name 'l_counter_collection.csv' | head -1)" "${TAG}_C2sq"
 echo "[5/5] LDS PMC pass done"
+
+# kernel stats of the other BASELINE configurations that fit one GPU (no PMC passes)
+for cfg in C3 C4shard C5shard; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$cfg" -o x -- python3 $B --config $cfg --steps 10 > "$OUT/$cfg.log" 2>&1
+    cp "$(find "$OUT/$cfg" -name 'x_kernel_stats.csv' | head -1)" "profiles/${TAG}_${cfg}_kernel_stats.csv"
+    echo "[+] $cfg kernel stats done"
+done
