@@ -428,7 +428,7 @@ int rbl_create(const rbl_config* cfg, rbl_solver** out) {
     h->storage = cfg->storage;
     h->esz = cfg->storage == RBL_STORE_F32 ? 4 : 8;
     h->sorted_path = cfg->weight_function != RBL_W_ERM;
-    if (h->cfg.tol <= 0.0) h->cfg.tol = 1e-4;
+    // tol is taken literally, as the reference does (algorithms.py:137): tol <= 0 never reports convergence
     if (h->cfg.w_tol <= 0.0) h->cfg.w_tol = 1e-13;
     if (h->cfg.max_iter <= 0) h->cfg.max_iter = 200;
     hipDeviceProp_t prop;

@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--phase-times", action="store_true",
                     help="HIP events around every phase (config.phase_ms_last); costs ~5 us of stream time per event")
     ap.add_argument("--seed", type=int, default=17)
+    ap.add_argument("--sharded-driver", action="store_true",
+                    help="N=1 only: run the multi-GPU driver (ShardedADMM over a 1-rank RCCL group) instead of the "
+                         "single handle, to measure the driver's own per-iteration cost")
     a = ap.parse_args()
 
     import torch
@@ -147,8 +150,10 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    if world > 1:
+    sharded = world > 1 or a.sharded_driver
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29733")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if _lib.device_count() < 1:
@@ -161,7 +166,7 @@ def main():
     s = rbl.Solver(n_local, d, cfg["weight_function"], cfg["loss"], reg=cfg["reg"], wstep=cfg["wstep"], B=cfg["B"],
                    args=cfg["args"], storage=a.storage, device=local_rank, n_total=n_total, row_offset=off,
                    tol=0.0)   # tol 0: a fixed number of iterations, never "converged"
-    if world > 1:
+    if sharded:
         drv = ShardedADMM(GpuEngine(s, local_rank))
         drv.setup_synthetic(a.seed)
         drv.setup_gram()
@@ -225,7 +230,7 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["label"], "rows": n_total, "cols": d, "storage": a.storage,
-                       "sharding": f"rows/{world}", "setup_s": round(t_setup, 3),
+                       "sharding": f"rows/{world}", "driver": "ShardedADMM" if sharded else "single handle", "setup_s": round(t_setup, 3),
                        "inner_iters_last": int(last.inner_iters), "phase_ms_last": ({
                            "z": round(last.ms_z, 3), "q": round(last.ms_q, 3), "w": round(last.ms_w, 3),
                            "v": round(last.ms_v, 3), "total": round(last.ms_total, 3)} if a.phase_times else None),

@@ -69,7 +69,8 @@ typedef struct rbl_config {
     double  reg;            /* l1_reg or l2_reg (algorithms.py:30) */
     double  smooth_t;       /* smoothADMMmethod t (algorithms.py:225,228) */
     double  rho0;           /* <= 0: reference default by weight_function (algorithms.py:47-52) */
-    double  tol;            /* stop tolerance (algorithms.py:44,137) */
+    double  tol;            /* stop tolerance (algorithms.py:44,137; reference default 1e-4); taken literally:
+                               tol <= 0 never reports convergence (a fixed number of iterations) */
     double  w_tol;          /* inner w-step tolerance; <= 0: library default 1e-13 */
     int32_t max_iter;       /* algorithms.py:45 */
     int32_t storage;        /* RBL_STORE_* */
