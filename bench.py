@@ -56,8 +56,9 @@ CONFIGS = {
 def cpu_baseline(cfg, seconds_budget=20.0):
     """Reference-faithful CPU mode (oracle/admm.py mode='faithful': fp32 n-space FISTA with
     backtracking, batch Newton prox, sweep PAV - the reference's own structure) on a
-    60 000-row sample of the workload; per-iteration cost is linear in n,
-    so it/s is scaled by sample_rows / rows."""
+    sample of the workload's rows (at most 60 000, fewer when a 2 000-row probe says that would exceed
+    the time budget); per-iteration cost is linear in n, so it/s is scaled by
+    sample_rows / rows."""
     import numpy as np
     from oracle import problems, admm
     try:
@@ -65,12 +66,19 @@ def cpu_baseline(cfg, seconds_budget=20.0):
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         cores = os.cpu_count() or 1
-    n_s = min(60_000, cfg["rows"])
     d = cfg["cols"]
-    X, y = problems.make_problem(n_s, d, seed=17)
     kw = dict(weight_function=cfg["weight_function"], loss=cfg["loss"], args=cfg["args"], B=cfg["B"])
     kw["l1_reg" if cfg["wstep"] == 1 else "l2_reg"] = cfg["reg"]
     iters = 6
+    # size the sample for about seconds_budget of CPU work: a 2 000-row probe gives the cost per row and
+    # iteration (the reference's EHRM z-step, Newton systems inside a Python PAV loop, is ~100x the others)
+    n_p = min(2_000, cfg["rows"])
+    X, y = problems.make_problem(n_p, d, seed=17)
+    t0 = time.perf_counter()
+    admm.admm_solve(X, y, max_iter=2, mode="faithful", store=False, tol=0.0, **kw)
+    per_row_iter = (time.perf_counter() - t0) / (2 * n_p)
+    n_s = int(min(60_000, cfg["rows"], max(n_p, seconds_budget / (iters * per_row_iter))))
+    X, y = problems.make_problem(n_s, d, seed=17)
     t0 = time.perf_counter()
     tr = admm.admm_solve(X, y, max_iter=iters, mode="faithful", store=False, tol=0.0, **kw)
     dt = time.perf_counter() - t0
@@ -250,7 +258,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 
