@@ -1572,7 +1572,7 @@ int rbl_risk_from_v(rbl_solver* h, const void* v_all_dev, double* out) {
 }
 
 int rbl_kernel_time(rbl_solver* h, int which, double* total_ms, int64_t* launches) {
-    RBL_ENTER(h);
+    RBL_ENTER_ITER(h);   // bookkeeping only: a w-step in flight stays
     if (which < 0 || which > 2) return RBL_ERR_INVALID;
     if (total_ms) *total_ms = h->kt_ms[which];
     if (launches) *launches = h->kt_n[which];
@@ -1580,14 +1580,14 @@ int rbl_kernel_time(rbl_solver* h, int which, double* total_ms, int64_t* launche
 }
 
 int rbl_reset_kernel_times(rbl_solver* h) {
-    RBL_ENTER(h);
+    RBL_ENTER_ITER(h);   // bookkeeping only: a w-step in flight stays
     h->kt_ms[0] = h->kt_ms[1] = h->kt_ms[2] = 0.0;
     h->kt_n[0] = h->kt_n[1] = h->kt_n[2] = 0;
     return RBL_OK;
 }
 
 int rbl_profile_kernels(rbl_solver* h, int enable) {
-    RBL_ENTER(h);
+    RBL_ENTER_ITER(h);   // bookkeeping only: a w-step in flight stays
     h->profile = enable != 0;
     h->phase_timing = enable >= 2;
     RBL_HIP(hipStreamSynchronize(h->stream));
@@ -1597,7 +1597,7 @@ int rbl_profile_kernels(rbl_solver* h, int enable) {
 // SPD, DI, EOD, AOD, TI, FNRD of the linear classifier on this handle's rows
 // (src/util/fair_metric.py:3-41); group: n doubles with values 0 / 1
 int rbl_profile_sampling(rbl_solver* h, int every) {
-    RBL_ENTER(h);
+    RBL_ENTER_ITER(h);   // bookkeeping only: a w-step in flight stays
     if (every < 1) {
         rbl_set_error("profile_sampling: every must be >= 1");
         return RBL_ERR_INVALID;
@@ -1660,13 +1660,13 @@ int rbl_fair_statistics(rbl_solver* h, const double* w, const double* group, dou
 // which part of the exchange buffer (RBL_BUF_Q) has to be summed over the ranks right now:
 // bit 0 = q part [0, 2 ld + 1), bit 1 = residual part [2 ld + 1, 2 ld + 3)
 int rbl_pending_reduce(rbl_solver* h, int* mask) {
-    RBL_ENTER(h);
+    RBL_ENTER_ITER(h);   // bookkeeping only: a w-step in flight stays
     if (mask) *mask = h->pending_mask;
     return RBL_OK;
 }
 
 int rbl_info(rbl_solver* h, int64_t* ld, int* num_cu, double* lipschitz) {
-    RBL_ENTER(h);
+    RBL_ENTER_ITER(h);   // bookkeeping only: a w-step in flight stays
     if (ld) *ld = h->ld;
     if (num_cu) *num_cu = h->num_cu;
     if (lipschitz) *lipschitz = h->L;
