@@ -213,9 +213,12 @@ class ShardedADMM:
         self._gather = None
         self.dist_z = bool(dist_z) and hasattr(engine, "zd_sort_local")
         self._stage = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        # a 1-rank group normally skips its (identity) all-reduces; bench.py --sharded-driver sets this
+        # to issue them anyway and time the collective's launch path on a 1-GPU box
+        self.always_allreduce = False
 
     def _allreduce(self, t):
-        if self.world > 1 and t.numel() > 0:
+        if (self.world > 1 or self.always_allreduce) and t.numel() > 0:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def _allgather_rows(self, local):

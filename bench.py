@@ -176,6 +176,7 @@ def main():
                    tol=0.0)   # tol 0: a fixed number of iterations, never "converged"
     if sharded:
         drv = ShardedADMM(GpuEngine(s, local_rank))
+        drv.always_allreduce = a.sharded_driver
         drv.setup_synthetic(a.seed)
         drv.setup_gram()
         step = lambda: drv.step(False)
