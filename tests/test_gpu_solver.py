@@ -239,6 +239,34 @@ def test_w_step_ahead_of_the_host_is_invisible(R):
     assert np.array_equal(np.array(r["h"]), h0) and np.array_equal(np.array(r["w"]), st0["w"])
 
 
+def test_stop_tolerance_is_literal(R):
+    """algorithms.py:137 stops when both residuals are below tol.  The library takes tol literally:
+    with the reference default it reports convergence at the iteration the oracle stops at; with
+    tol = 0 it never does, and a fixed-length run stays in the single-sweep steady state past that
+    point (a library-side default for tol <= 0 once made such runs fall out of it)."""
+    from oracle import problems, admm
+    # d = 140: fp64 rows of more than 32 16-byte packets, the narrowest the single-sweep kernel takes
+    # (sweep_erm.hip: sweep_erm_supported); narrower problems run the two-sweep path and never set "fused"
+    X, y = problems.make_problem(3000, 140, seed=21)
+    kw = dict(weight_function="erm", loss="binary_cross_entropy", l1_reg=0.01)
+    ref = admm.admm_solve(X, y, max_iter=400, mode="exact", tol=1e-4, **kw)
+    assert ref.converged and 20 < ref.iters < 400
+    s = R.ADMMmethod(X, y, max_iter=400, tol=1e-4, storage="f64", **kw)._s
+    stop = None
+    for k in range(400):
+        if s.step(False).converged:
+            stop = k + 1
+            break
+    assert stop == ref.iters
+    s0 = R.ADMMmethod(X, y, max_iter=400, tol=0.0, storage="f64", **kw)._s
+    total = ref.iters + 40
+    flags = [(st.converged, st.fused, st.mispredicted) for st in (s0.step(False) for _ in range(total))]
+    assert not any(f[0] for f in flags)
+    assert all(f[1] for f in flags) and sum(f[2] for f in flags) <= 2
+    w_ref = admm.admm_solve(X, y, max_iter=total, mode="exact", tol=0.0, **kw).w
+    assert np.max(np.abs(s0.get_state()["w"] - w_ref)) <= 1e-10 * max(1.0, np.max(np.abs(w_ref)))
+
+
 def test_objective_golden_g7(R):
     g = load_golden("g7_objective.npz")
     X, y, w = g["X"], g["y"], g["w"]
