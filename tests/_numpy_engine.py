@@ -207,3 +207,114 @@ class NumpyEngine:
         z = np.empty(self.n_local)
         z[ids] = u
         self.z = z
+
+
+class FusedNumpyEngine(NumpyEngine):
+    """erm only: the exchange protocol of librbl's single-sweep iteration (csrc/api.hip: rbl_phase_* with
+    fused_ok) restated in NumPy, so that the CPU gloo tests reach dist.py's ``pending_reduce`` branches:
+
+    * ONE exchange buffer ``[q (d) | D^T lambda seed (d) | ||z||^2 | primal^2 | sum loss]``; ``buf("q")`` is the
+      whole buffer, ``buf("red")`` a view of its 2-double tail;
+    * the pass of iteration k (phase_dual) also does iteration k+1's z-step and q = D^T c with the rho
+      PREDICTED in d-space from global sums (||z - D w||^2 = ||z||^2 - 2 (D^T z)^T w + w^T G w with
+      D^T z = q - (D^T lambda)/rho and D^T lambda kept by the recurrence p += rho (D^T z - G w));
+      ``pending_reduce()`` is then 3: one collective over the whole buffer;
+    * phase_finish verifies the prediction against the exact residual; on a mismatch the next iteration runs
+      the two-sweep path (pending masks 1 and 2).  ``mispredict_every`` corrupts predictions on purpose."""
+
+    def __init__(self, *a, mispredict_every=0, **k):
+        super().__init__(*a, **k)
+        assert not self.sorted_path and self.l1 is not None
+        d = self.d
+        self.x = torch.zeros(2 * d + 3, dtype=torch.float64)
+        self.bufs["q"] = self.x
+        self.bufs["red"] = self.x[2 * d + 1:]
+        self.z_ready = self.p_valid = self.p_pending = self.pred_valid = False
+        self.v_valid = False
+        self.mask = 0
+        self.mis_every = mispredict_every
+        self.n_fused = self.n_mispred = 0
+
+    def pending_reduce(self):
+        return self.mask
+
+    def _xs(self):
+        return self.x.numpy()
+
+    def phase_m(self):
+        if self.z_ready:
+            return
+        if not self.v_valid:
+            self.v = self.D @ self.w
+            self.v_valid = True
+        self.bufs["m"].copy_(torch.from_numpy(self.v - self.lam / self.rho))
+
+    def phase_z(self, m_all):
+        d = self.d
+        if self.z_ready:
+            self.z = self.z_next
+        else:
+            self.z = prox.prox_exact(self.loss, self.sa[0], self.rho, self.bufs["m"].numpy())
+            self._xs()[2 * d] = float(self.z @ self.z)
+
+    def phase_q(self):
+        d, x = self.d, self._xs()
+        if not self.z_ready:
+            x[:d] = self.D.T @ (self.z + self.lam / self.rho)
+            if not self.p_valid:
+                x[d:2 * d] = self.D.T @ self.lam
+                self.p_pending = True
+        self.mask = 0 if self.z_ready else 1
+        self.z_ready = False
+
+    def phase_w(self):
+        d, x = self.d, self._xs()
+        if self.p_pending:
+            self.p = x[d:2 * d].copy()
+            self.p_pending, self.p_valid = False, True
+        q = x[:d].copy()
+        self.w_prev = self.w.copy()
+        if self.l1:
+            self.w, _ = wstep.lasso_gram_exact(self.G, q, self.reg / (2 * self.rho), self.w, self.L)
+        else:
+            self.w = wstep.ridge_gram_exact(self.G, q, self.rho, self.reg)
+        self.pred_valid = False
+        if self.p_valid:
+            Gw = self.G @ self.w
+            Dtz = q - self.p / self.rho
+            r2 = x[2 * d] - 2.0 * float(Dtz @ self.w) + float(self.w @ Gw)
+            self.p = self.p + self.rho * (Dtz - Gw)
+            self.rho_pred = admm.next_rho(self.rho, float(np.sqrt(max(r2, 0.0))), self.d)
+            if self.mis_every and self.iter % self.mis_every == self.mis_every - 1:
+                self.rho_pred = self.rho * 1.5
+            self.pred_valid = True
+
+    def phase_dual(self, want_objective):
+        d, x = self.d, self._xs()
+        self.v = self.D @ self.w
+        self.v_valid = True
+        self.bufs["v"].copy_(torch.from_numpy(self.v))
+        r = self.z - self.v
+        self.lam = self.lam + self.rho * r
+        x[2 * d + 1] = float(r @ r)
+        x[2 * d + 2] = float(np.sum(objective.sample_losses(self.loss, self.v)))
+        self.fused_ran = self.pred_valid
+        if self.fused_ran:        # the same pass: iteration k+1's z-step and q with the predicted rho
+            rp = self.rho_pred
+            self.z_next = prox.prox_exact(self.loss, self.sa[0], rp, self.v - self.lam / rp)
+            x[:d] = self.D.T @ (self.z_next + self.lam / rp)
+            x[2 * d] = float(self.z_next @ self.z_next)
+        self.mask = 2 | (1 if self.fused_ran else 0)
+        self.want = want_objective
+
+    def phase_finish(self):
+        st = super().phase_finish()          # reads the summed tail through bufs["red"]; applies the rho rule
+        st.fused = int(self.fused_ran)
+        st.mispredicted = 0
+        if self.fused_ran:
+            self.z_ready = (not st.converged) and self.rho_pred == self.rho
+            st.mispredicted = int((not st.converged) and not self.z_ready)
+            self.n_fused += 1
+            self.n_mispred += st.mispredicted
+        self.pred_valid = False
+        return st

@@ -20,6 +20,17 @@ CFGS = [
 ]
 
 
+def _oracle_on_device_data(s, cfg):
+    """the CPU oracle (exact mode) on the rows the device generator produced: D = -y X is pulled with
+    get_D() (fp32 storage: the stored, rounded values), so both sides see the same matrix"""
+    from oracle import admm
+    D, y = s.get_D(), s.labels()
+    kw = dict(weight_function=cfg["wf"], loss=cfg["loss"], args=cfg.get("args"), B=cfg.get("B"))
+    kw["l1_reg" if cfg["wstep"] == 1 else "l2_reg"] = cfg["reg"]
+    ref = admm.admm_solve(-y[:, None] * D, y.reshape(-1, 1), max_iter=cfg["iters"], mode="exact", tol=0.0, **kw)
+    return dict(o_w=ref.w, o_z=ref.z, o_hist=np.array([ref.primal, ref.dual, ref.rho, ref.objective[1:]]).T)
+
+
 def _run(rank, world, port, cfg, out):
     sys.path.insert(0, ROOT)
     if world > 1:
@@ -35,16 +46,20 @@ def _run(rank, world, port, cfg, out):
     try:
         lo, cnt, _ = shard_rows(cfg["n"], world, rank)
         s = rbl.Solver(cnt, cfg["d"], cfg["wf"], cfg["loss"], reg=cfg["reg"], wstep=cfg["wstep"], B=cfg.get("B"),
-                       args=cfg.get("args"), n_total=cfg["n"], row_offset=lo, tol=0.0, storage="f64")
+                       args=cfg.get("args"), n_total=cfg["n"], row_offset=lo, tol=0.0, storage=cfg.get("storage", "f64"))
         drv = ShardedADMM(GpuEngine(s, 0), dist_z=cfg.get("dist_z", True))
         drv.setup_synthetic(seed=11)
         drv.setup_gram()
-        hist = []
+        hist, flags = [], []
         for _ in range(cfg["iters"]):
             st = drv.step(True)
             hist.append((st.primal, st.dual, st.rho, st.objective))
+            flags.append((st.fused, st.mispredicted))
         state = s.get_state()
-        np.savez(out % rank, w=state["w"], z=state["z"], hist=np.array(hist), lo=lo)
+        extra = {}
+        if world == 1 and cfg.get("oracle"):
+            extra = _oracle_on_device_data(s, cfg)
+        np.savez(out % rank, w=state["w"], z=state["z"], hist=np.array(hist), lo=lo, flags=np.array(flags), **extra)
     finally:
         if world > 1:
             dist.destroy_process_group()
@@ -65,8 +80,8 @@ MORE = [
 
 
 MORE += [
-    # every 3rd rho prediction corrupted on both ranks: the verification + two-sweep redo (and its two
-    # partial all-reduces) inside the sharded driver
+    # d = 48 is too narrow for the single-sweep kernel: the two-sweep iteration, on which the debug
+    # variable must have no effect (the corrupted-prediction path is covered by FUSED below)
     (2, dict(n=40000, d=48, wf="erm", loss="binary_cross_entropy", reg=0.01, wstep=1, iters=9,
              env={"RBL_DEBUG_MISPREDICT_EVERY": "3"})),
     (4, dict(n=5, d=3, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=4)),   # rank 3 owns no row
@@ -74,8 +89,38 @@ MORE += [
 ]
 
 
+# erm problems wide enough for the single-sweep kernel (sweep_erm.hip: sweep_erm_supported needs more than 32
+# 16-byte packets per row: d >= 132 in fp32 storage, d >= 66 in fp64): the ONE-collective iteration of
+# dist.py (pending mask 3: [q | seed | ||z||^2 | primal^2 | loss] summed after the pass, rho predicted from global
+# sums) - the path `bench.py --gpus N` takes for C2 / C5
+FUSED = [
+    (2, dict(n=40000, d=160, wf="erm", loss="binary_cross_entropy", reg=0.01, wstep=1, iters=9, storage="f64",
+             fused=True, oracle=True)),
+    (4, dict(n=40000, d=160, wf="erm", loss="hinge", reg=0.01, wstep=2, iters=9, storage="f64", fused=True, oracle=True)),
+    (2, dict(n=20000, d=1000, wf="erm", loss="binary_cross_entropy", reg=0.01, wstep=1, iters=8, storage="f32",
+             fused=True, oracle=True)),
+    (4, dict(n=20001, d=1000, wf="erm", loss="hinge", reg=0.01, wstep=2, iters=8, storage="f32", fused=True, oracle=True)),
+    (3, dict(n=9000, d=1100, wf="erm", loss="binary_cross_entropy", reg=0.01, wstep=1, iters=8, storage="f32",
+             fused=True, oracle=True)),       # workgroup-per-row kernel, uneven shards
+    # every 3rd rho prediction corrupted on every rank: verification, two-sweep redo and its two partial
+    # all-reduces in between single-collective iterations
+    (2, dict(n=40000, d=160, wf="erm", loss="binary_cross_entropy", reg=0.01, wstep=1, iters=10, storage="f64",
+             fused=True, mispredict=True, oracle=True, env={"RBL_DEBUG_MISPREDICT_EVERY": "3"})),
+]
+
+
+@pytest.mark.parametrize("world,cfg", FUSED, ids=["bce_l1_f64_w2", "hinge_l2_f64_w4", "bce_l1_f32_d1000_w2",
+                                                   "hinge_l2_f32_d1000_w4", "bce_l1_f32_wide_w3", "mispredict_w2"])
+def test_single_collective_erm_iteration_multi_rank(world, cfg, tmp_path):
+    """The fused single-sweep erm iteration with more than one rank: every rank reports fused = 1 on every
+    iteration, the ranks stay bit-identical, the iterates equal the single-handle run (1e-9) AND the CPU
+    oracle's exact mode on the same (device-generated, get_D()-pulled) data.  Reference:
+    src/optim/algorithms.py:119-157."""
+    _check(cfg, world, tmp_path)
+
+
 @pytest.mark.parametrize("world,cfg", MORE, ids=["superq_w4", "aorr_hinge_w3", "ehrm_w4", "extremile_replicated_z",
-                                                  "erm_mispredictions_w2", "tiny_with_an_empty_rank", "esrm_hinge_l1_w3"])
+                                                  "erm_two_sweep_debug_env_w2", "tiny_with_an_empty_rank", "esrm_hinge_l1_w3"])
 def test_distributed_z_step_on_device(world, cfg, tmp_path):
     """rank-weighted problems with the sorted order partitioned over 3 / 4 ranks on the device path
     (rbl_zd_*: sample sort, chunk PAV, merge tree over ranks), and the replicated all-gather form."""
@@ -103,6 +148,28 @@ def _check(cfg, world, tmp_path):
     assert np.max(np.abs(r0["w"] - one["w"])) <= 1e-9 * max(1.0, np.max(np.abs(one["w"])))
     assert np.max(np.abs(z2 - one["z"])) <= 1e-8 * max(1.0, np.max(np.abs(one["z"])))
     assert np.allclose(r0["hist"], one["hist"], rtol=1e-8, atol=1e-12)
+    _check_fused_and_oracle(cfg, one, rs, z2)
+
+
+def _check_fused_and_oracle(cfg, one, rs, z_all):
+    if cfg.get("fused"):
+        for r in rs:
+            fl = r["flags"]
+            assert np.all(fl[:, 0] == 1), fl.tolist()         # the single-collective path ran on every iteration
+            if cfg.get("mispredict"):
+                assert fl[:, 1].sum() >= 3                     # the corrupted predictions were caught on this rank
+            else:
+                assert fl[:, 1].sum() == 0
+            assert np.array_equal(fl, rs[0]["flags"])
+        assert np.all(one["flags"][:, 0] == 1)
+    if cfg.get("oracle"):
+        tol = 1e-9 if cfg["loss"] == "binary_cross_entropy" else 1e-7    # hinge: kinks amplify rounding
+        ow, oz, oh = one["o_w"], one["o_z"], one["o_hist"]
+        for got_w, got_z, got_h in ((one["w"], one["z"], one["hist"]), (rs[0]["w"], z_all, rs[0]["hist"])):
+            assert np.max(np.abs(got_w - ow)) <= tol * max(1.0, np.max(np.abs(ow)))
+            assert np.max(np.abs(got_z - oz)) <= 10 * tol * max(1.0, np.max(np.abs(oz)))
+            assert np.allclose(got_h[:, 2], oh[:, 2], rtol=1e-15)
+            assert np.allclose(got_h[:, [0, 1, 3]], oh[:, [0, 1, 3]], rtol=tol, atol=tol)
 
 
 def test_rccl_accepts_the_library_views_one_rank():
@@ -191,16 +258,17 @@ def _thread_rank(rank, world, cfg, hub, out, errs):
         torch.cuda.set_device(0)
         lo, cnt, _ = shard_rows(cfg["n"], world, rank)
         s = rbl.Solver(cnt, cfg["d"], cfg["wf"], cfg["loss"], reg=cfg["reg"], wstep=cfg["wstep"], B=cfg.get("B"),
-                       args=cfg.get("args"), n_total=cfg["n"], row_offset=lo, tol=0.0, storage="f64")
+                       args=cfg.get("args"), n_total=cfg["n"], row_offset=lo, tol=0.0, storage=cfg.get("storage", "f64"))
         drv = _make_thread_driver(ShardedADMM, hub)(GpuEngine(s, 0), world=world, rank=rank)
         drv.setup_synthetic(seed=11)
         drv.setup_gram()
-        hist = []
+        hist, flags = [], []
         for _ in range(cfg["iters"]):
             st = drv.step(True)
             hist.append((st.primal, st.dual, st.rho, st.objective))
+            flags.append((st.fused, st.mispredicted))
         state = s.get_state()
-        out[rank] = dict(w=state["w"], z=state["z"], hist=np.array(hist))
+        out[rank] = dict(w=state["w"], z=state["z"], hist=np.array(hist), flags=np.array(flags))
     except BaseException as e:       # a dead thread must not leave the others in a barrier forever
         errs.append((rank, repr(e)))
         hub.bar.abort()
@@ -211,10 +279,14 @@ def _thread_rank(rank, world, cfg, hub, out, errs):
     dict(n=40000, d=21, wf="ehrm", B=-5.0, loss="binary_cross_entropy", reg=0.01, wstep=2, iters=5),
     dict(n=30011, d=21, wf="aorr", args=[0.2, 0.8], loss="hinge", reg=1e-4, wstep=2, iters=6),
     dict(n=40000, d=48, wf="erm", loss="binary_cross_entropy", reg=0.01, wstep=1, iters=8),
-], ids=["superq", "ehrm", "aorr_hinge", "erm"])
+    dict(n=40003, d=160, wf="erm", loss="binary_cross_entropy", reg=0.01, wstep=1, iters=9, storage="f64", fused=True,
+         oracle=True),
+    dict(n=16000, d=1000, wf="erm", loss="hinge", reg=0.01, wstep=2, iters=8, storage="f32", fused=True, oracle=True),
+], ids=["superq", "ehrm", "aorr_hinge", "erm_two_sweep", "erm_single_collective_f64", "erm_single_collective_f32_d1000"])
 def test_eight_ranks_as_threads_match_single_handle(cfg, tmp_path):
-    """the 8-rank protocol (three levels of the merge tree over ranks, all-to-all exchanges, the
-    single-collective erm iteration) on the device path against the single-handle run"""
+    """the 8-rank protocol (three levels of the merge tree over ranks, all-to-all exchanges; erm: the
+    two-sweep iteration at d = 48, where the single-sweep kernel does not apply, and the single-collective
+    iteration at d = 160 / 1000) on the device path against the single-handle run and the oracle"""
     import threading
     import torch.multiprocessing as mp
     sys.path.insert(0, ROOT)
@@ -242,3 +314,4 @@ def test_eight_ranks_as_threads_match_single_handle(cfg, tmp_path):
     assert np.max(np.abs(out[0]["w"] - one["w"])) <= 1e-9 * max(1.0, np.max(np.abs(one["w"])))
     assert np.max(np.abs(z8 - one["z"])) <= 1e-8 * max(1.0, np.max(np.abs(one["z"])))
     assert np.allclose(out[0]["hist"], one["hist"], rtol=1e-8, atol=1e-12)
+    _check_fused_and_oracle(cfg, one, out, z8)

@@ -99,8 +99,13 @@ def _worker(rank, world, port, cfg, out):
         from oracle import problems
         X, y = problems.make_problem(cfg["n"], cfg["d"], cfg["seed"])
         lo, cnt, _ = shard_rows(cfg["n"], world, rank)
-        eng = NumpyEngine(X[lo:lo + cnt], y[lo:lo + cnt], cfg["n"], lo, cfg["wf"], cfg["loss"], cfg["reg"], cfg["l1"],
-                          B=cfg.get("B"), args=cfg.get("args"))
+        if cfg.get("fused"):
+            from _numpy_engine import FusedNumpyEngine
+            eng = FusedNumpyEngine(X[lo:lo + cnt], y[lo:lo + cnt], cfg["n"], lo, cfg["wf"], cfg["loss"], cfg["reg"],
+                                   cfg["l1"], mispredict_every=cfg.get("mispredict_every", 0))
+        else:
+            eng = NumpyEngine(X[lo:lo + cnt], y[lo:lo + cnt], cfg["n"], lo, cfg["wf"], cfg["loss"], cfg["reg"], cfg["l1"],
+                              B=cfg.get("B"), args=cfg.get("args"))
         drv = ShardedADMM(eng, dist_z=cfg.get("dist_z", True))
         drv.setup_gram()
         hist = []
@@ -108,7 +113,8 @@ def _worker(rank, world, port, cfg, out):
             st = drv.step(want_objective=True)
             hist.append((st.primal, st.dual, st.rho, st.objective))
         if rank == 0:
-            np.savez(out, w=eng.w, hist=np.array(hist))
+            np.savez(out, w=eng.w, hist=np.array(hist),
+                     fused=getattr(eng, "n_fused", 0), mispred=getattr(eng, "n_mispred", 0))
     finally:
         dist.destroy_process_group()
 
@@ -121,6 +127,25 @@ def _worker(rank, world, port, cfg, out):
 ], ids=["erm_l1", "superq_l2_uneven", "aorr_hinge", "ehrm"])
 def test_sharded_driver_world2_gloo_matches_single_process(cfg, tmp_path):
     _check_sharded(cfg, 2, tmp_path)
+
+
+@pytest.mark.parametrize("world,cfg", [
+    (2, dict(n=600, d=12, seed=3, wf="erm", loss="binary_cross_entropy", reg=0.01, l1=True, iters=14, fused=True)),
+    (3, dict(n=701, d=10, seed=13, wf="erm", loss="hinge", reg=0.01, l1=False, iters=14, fused=True)),
+    (2, dict(n=600, d=12, seed=3, wf="erm", loss="binary_cross_entropy", reg=0.01, l1=True, iters=14, fused=True,
+             mispredict_every=3)),
+], ids=["bce_l1_world2", "hinge_l2_world3", "mispredict_world2"])
+def test_single_collective_erm_iteration_gloo(world, cfg, tmp_path):
+    """dist.py's `pending_reduce` branches (mask 1 / 2 slices, mask 3 = ONE all-reduce of the whole exchange
+    buffer after the pass, rho predicted from global sums) on the NumPy restatement of librbl's
+    single-sweep protocol (tests/_numpy_engine.py: FusedNumpyEngine), world_size 2 / 3 over gloo, against
+    the single-process oracle."""
+    got = _check_sharded(cfg, world, tmp_path)
+    assert int(got["fused"]) == cfg["iters"]
+    if cfg.get("mispredict_every"):
+        assert int(got["mispred"]) >= 3
+    else:
+        assert int(got["mispred"]) <= 1       # only a residual within rounding of the 1e-2 threshold can mispredict
 
 
 @pytest.mark.parametrize("world,cfg", [
@@ -157,3 +182,4 @@ def _check_sharded(cfg, world, tmp_path):
     assert np.allclose(hist[:, 1], ref.dual, rtol=1e-9, atol=1e-12)
     assert np.allclose(hist[:, 2], ref.rho, rtol=1e-15)
     assert np.allclose(hist[:, 3], ref.objective[1:], rtol=1e-9)
+    return got
