@@ -97,6 +97,9 @@ struct rbl_solver {
     hipEvent_t ev_spec[2] = {nullptr, nullptr};
     bool phase_timing = false;   // rbl_profile_kernels level 2: HIP events around the phases (ms_* of rbl_stats)
     int64_t n_fused = 0, n_mispred = 0;
+    bool fused_v_ran = false;
+    int n_sync = 0;        // host waits inside the iteration in flight (rbl_stats.host_syncs)
+    int sort_passes = 0;   // radix passes executed by the z-step in flight
 };
 
 void rbl_spin_wait(const volatile int* word, int sentinel, hipStream_t stream) {
@@ -1008,6 +1011,7 @@ int rbl_phase_dual(rbl_solver* h, int want_objective) {
     RBL_ENTER_ITER(h);
 
     h->fused_ran = false;
+    h->fused_v_ran = false;
     if (h->fused_ok && h->pred_valid) {
         if (prof_now(h)) RBL_HIP(hipEventRecord(h->kev[4], h->stream));
         RBL_TRY(launch_sweep_erm(h->storage, h->cfg.loss, h->D, h->n, h->ld, h->w, h->z, h->lam, h->v, h->z_next,
@@ -1024,6 +1028,7 @@ int rbl_phase_dual(rbl_solver* h, int want_objective) {
                                h->num_cu, h->stream, prof_now(h) ? h->kev[1] : nullptr));
         if (prof_now(h)) h->kev_pending[0] = h->n > 0;
         h->v_valid = true;
+        h->fused_v_ran = true;
         if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[4], h->stream));
     } else {
         if (prof_now(h)) RBL_HIP(hipEventRecord(h->kev[0], h->stream));
@@ -1192,9 +1197,15 @@ int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
         out->ms_total = ms[4];
         out->fused = fused;
         out->mispredicted = mispred;
+        out->fused_v = h->fused_v_ran ? 1 : 0;
+        out->host_syncs = h->n_sync + 1;   // + the wait for the statistics block above
+        out->sort_passes = h->sorted_path ? h->sort_passes : -1;
+        out->reserved = 0;
     }
     h->rho = rho_next;
     h->iter = i + 1;
+    h->n_sync = 0;
+    h->sort_passes = 0;
     return RBL_OK;
 }
 

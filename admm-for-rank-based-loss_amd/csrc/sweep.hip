@@ -399,12 +399,17 @@ template <typename T>
 __global__ void k_standardize_negy(T* __restrict__ D, long long n, long long ld, long long d,
                                    const double* __restrict__ mean, const double* __restrict__ inv_std,
                                    const signed char* __restrict__ ysign) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * ld) return;
-    long long r = i / ld, j = i - r * ld;
-    if (j >= d) return;
-    double x = ((double)D[i] - mean[j]) * inv_std[j];
-    D[i] = (T)(-(double)ysign[r] * x);
+    // grid-stride: n * ld exceeds 2^32 at the full-size configurations (6e9 elements at C2), and a HIP
+    // launch of more than 2^32 threads wraps - round 1 launched one thread per element here and left the
+    // rows beyond the wrap unstandardised (caught by tests/test_gpu_fullsize.py)
+    const long long total = n * ld;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / ld, j = i - r * ld;
+        if (j >= d) continue;
+        const double x = ((double)D[i] - mean[j]) * inv_std[j];
+        D[i] = (T)(-(double)ysign[r] * x);
+    }
 }
 
 }  // namespace
@@ -483,10 +488,7 @@ int launch_standardize_negy(int storage, void* D, int64_t n, int64_t ld, int64_t
     long long total = n * ld;
     if (total <= 0) return RBL_OK;
     long long nblk = (total + 255) / 256;
-    if (nblk > 0x7fffffffLL) {
-        rbl_set_error("standardize: grid too large");
-        return RBL_ERR_INVALID;
-    }
+    if (nblk > (1 << 20)) nblk = 1 << 20;   // grid-stride kernel: at most 2^28 threads per launch
     if (storage == RBL_STORE_F32)
         hipLaunchKernelGGL(k_standardize_negy<float>, dim3((unsigned)nblk), dim3(256), 0, s, (float*)D, (long long)n,
                            (long long)ld, (long long)d, mean, inv_std, ysign);

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RBL_VERSION 100
+#define RBL_VERSION 101
 
 /* status codes */
 enum {
@@ -93,6 +93,12 @@ typedef struct rbl_stats {
     float   ms_z, ms_q, ms_w, ms_v, ms_total;  /* device time of the phases, HIP events (rbl_profile_kernels level 2) */
     int32_t fused;           /* 1: this iteration's dual update ran in the single-sweep erm kernel */
     int32_t mispredicted;    /* 1: rho was mispredicted, the next z-step is redone unfused */
+    int32_t fused_v;         /* 1: rank-weighted iteration whose v = D w, lambda update and primal residual ran in one
+                                pass (the v-only mode of the single-sweep kernel) instead of k_gemv + k_dual */
+    int32_t host_syncs;      /* times the host waited for the device inside this iteration's library calls
+                                (stream waits, blocking copies, the spin on the pinned statistics block) */
+    int32_t sort_passes;     /* radix-sort passes the z-step executed (digits shared by all keys are skipped), -1 = n/a */
+    int32_t reserved;
 } rbl_stats;
 
 typedef struct rbl_solver rbl_solver;

@@ -41,6 +41,9 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
     loss = "binary_cross_entropy" if fam == "ehrm" else ("binary_cross_entropy", "hinge")[int(rng.integers(2))]
     n = int(rng.integers(50, 70000))
     d = int(rng.integers(3, 50))
+    if rng.random() < 0.4:
+        d = int(rng.integers(66, 400))      # single-sweep erm / v-only kernels (fp64 storage: more than 32 packets)
+        n = int(rng.integers(50, 20000))
     world = int(rng.choice([2, 3, 5, 7, 8]))
     cfg = dict(n=n, d=d, wf=fam, loss=loss, args=args, reg=float(10.0 ** rng.uniform(-4, -1)),
                wstep=1 if (fam != "ehrm" and rng.random() < 0.4) else 2, iters=5)

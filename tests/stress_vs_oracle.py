@@ -1,9 +1,12 @@
 """Randomized whole-solver parity run (TEST INFRASTRUCTURE, not collected by pytest): random
 family / loss / regulariser / shape, 12 ADMM iterations on the GPU against the oracle's exact mode.
     python tests/stress_vs_oracle.py SEED TRIALS [MAX_ROWS]
-Round 1: 660 fp64 trials (seeds 1-5 and 7, rows up to 80 000), worst relative deviation 8e-14; 450
-more with 40 % fp32 storage and rows up to 2600 wide (seeds 11-13): fp64 as before, fp32 within 2e-4
-(EHRM, non-convex: 7e-4)."""
+fp32 storage is EXACT fp64 arithmetic on the fp32-rounded matrix: the oracle is fed the rounded X (what the
+device stores), so one tolerance (1e-8 BCE, 1e-6 hinge) holds for both storage types and every family.
+Against the UNROUNDED matrix (`RAW=1` in the environment) fp32 storage is a perturbed problem: round 1
+measured 2e-4 on the convex families over 12 iterations and up to 7e-4 (EHRM) / 5e-2 (AoRR) on the
+non-convex ones, whose trajectories amplify the 6e-8 relative perturbation of D.
+Round 1: 660 fp64 trials (seeds 1-5 and 7, rows up to 80 000), worst relative deviation 8e-14."""
 import os
 import sys
 import time
@@ -28,6 +31,9 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
         if rng.random() < 0.3:
             d = int(rng.integers(1030, 2600))    # workgroup-per-row kernel
             n = int(rng.integers(20, 600))
+    if fam != "erm" and rng.random() < 0.35:
+        d = int(rng.integers(130, 1030))         # v-only single-sweep kernel territory (all pass counts)
+        n = int(rng.integers(200, 2500))
     storage = "f32" if rng.random() < 0.4 else "f64"
     kw = dict(weight_function=fam, loss=loss, args=args)
     if fam == "ehrm": kw["B"] = -5
@@ -35,6 +41,9 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     regk = "l1_reg" if rng.random() < 0.4 and fam != "ehrm" else "l2_reg"
     kw[regk] = float(10.0 ** rng.uniform(-4, -1))
     X, y = problems.make_problem(n, d, seed=int(rng.integers(1 << 30)))
+    raw = os.environ.get("RAW") == "1"
+    if storage == "f32" and not raw:
+        X = X.astype(np.float32).astype(np.float64)      # the matrix the device stores
     nit = 12
     try:
         ref = admm.admm_solve(X, y, max_iter=nit, mode="exact", tol=0.0, **kw)
@@ -46,7 +55,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
         w = s._s.get_state()["w"]
         werr = np.max(np.abs(w - ref.w)) / max(1.0, np.max(np.abs(ref.w)))
         tol = 1e-8 if loss == "binary_cross_entropy" else 1e-6
-        if storage == "f32":
+        if storage == "f32" and raw:
             # D rounded to fp32 is a perturbed problem; the non-convex families amplify the perturbation
             tol = 5e-2 if fam in ("aorr", "aorr_dc") else (5e-3 if fam == "ehrm" else 2e-4)
         flag = "" if (worst <= tol and werr <= tol) else "  <<<<<< MISMATCH"

@@ -85,8 +85,9 @@ G9 = ["erm_bce_l1", "erm_bce_l2", "superq_bce_l2", "extremile_bce_l1", "esrm_hin
       "aorr_hinge_l2", "aorr_bce_l2", "ehrm_bce_l2", "sadmm_erm_bce_l1"]
 
 
+@pytest.mark.parametrize("storage", ["f64", "f32"])
 @pytest.mark.parametrize("name", G9)
-def test_reference_trajectory_goldens(R, name):
+def test_reference_trajectory_goldens(R, name, storage):
     """Whole solves vs the REAL reference (goldens).  Contract: runs that
     reach the stop rule agree on the final objective to 1e-6 relative (ehrm 2e-6); the
     initial objective and the rho schedule are identical; AoRR/hinge cannot be matched
@@ -104,7 +105,7 @@ def test_reference_trajectory_goldens(R, name):
     assert problems.sha256_of(X) == str(g["x_sha256"]) and problems.sha256_of(y) == str(g["y_sha256"])
     kw = cfg["kw"]
     cls = R.smoothADMMmethod if cfg["cls"] == "smoothADMMmethod" else R.ADMMmethod
-    s = cls(X, y, max_iter=cfg["max_iter"], storage="f64", **kw)
+    s = cls(X, y, max_iter=cfg["max_iter"], storage=storage, **kw)
     skw = {k: v for k, v in kw.items() if k != "B"}
     s.start_store(X, y, **skw)
     w = _quiet(s.main_loop, verbose=False)
@@ -112,10 +113,10 @@ def test_reference_trajectory_goldens(R, name):
     f_gpu = s.objective.get_arrogate_loss(w)
     ref_obj = g["objective"]
     # same initial point and objective definition: F(w0) identical
-    assert abs(s.train_losses[0] - ref_obj[0]) <= 1e-12 * abs(ref_obj[0])
+    assert abs(s.train_losses[0] - ref_obj[0]) <= (1e-12 if storage == "f64" else 1e-7) * abs(ref_obj[0])
     rel = (f_gpu - f_ref) / abs(f_ref)
     converged_ref = bool(g["converged"])
-    print(f"{name}: F_gpu={f_gpu:.12g} F_ref={f_ref:.12g} rel={rel:+.2e} iters gpu={len(s.train_losses)-1} ref={int(g['iters'])}")
+    print(f"{name} [{storage}]: F_gpu={f_gpu:.12g} F_ref={f_ref:.12g} rel={rel:+.2e} iters gpu={len(s.train_losses)-1} ref={int(g['iters'])}")
     if name == "sadmm_erm_bce_l1":
         # the smoothed problem's own optimum: both within the smoothing error of each other
         assert abs(rel) <= 2e-3

@@ -1,0 +1,170 @@
+"""Parity at the row widths the bench configurations use (the bench kernels were only
+compared with the oracle at d <= 90).
+
+* rank-weighted iterations at d in {100 ... 1001}: every instance of the v-only single-sweep kernel
+  (sweep_erm.hip: RBL_V(P, R, S), P = 1 / 2 / 4 passes of 64 packets in fp32 storage and 1 / 2 / 4 / 8 in
+  fp64) against the oracle's exact mode AND against the unfused k_gemv + k_dual path (RBL_NO_FUSE=1), with
+  and without row tails (super-batches are 16 rows), both storage types.  fp32 cases are fed
+  fp32-representable X, so the oracle sees exactly the stored matrix.
+  Reference: src/optim/algorithms.py:88-106 (z-step), :132-136 (dual update, residuals).
+* C5's width: Gram / lasso / whole iterations at d = 10 000 and 4 100 (workgroup-per-row kernel).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    import admm_for_rank_based_loss_amd as rbl
+    if rbl._lib.device_count() < 1:
+        pytest.fail("no HIP device: the GPU tests must run the HIP library (no fallback)")
+    return rbl
+
+
+FAM = {
+    "superq": dict(weight_function="superquantile", loss="binary_cross_entropy", l2_reg=0.01, args=[0.5]),
+    "aorr_hinge": dict(weight_function="aorr", loss="hinge", l2_reg=1e-4, args=[0.2, 0.8]),
+    "ehrm": dict(weight_function="ehrm", loss="binary_cross_entropy", l2_reg=0.01, B=-5),
+    "extremile_l1": dict(weight_function="extremile", loss="binary_cross_entropy", l1_reg=0.01, args=[2.0]),
+}
+
+# (family, rows, columns, intercept column, storage) -> v-only instance in the comment
+WIDTHS = [
+    ("superq", 3001, 100, False, "f64"),      # fp64 P=1
+    ("superq", 3000, 140, False, "f32"),      # fp32 P=1
+    ("superq", 2999, 140, False, "f64"),      # fp64 P=2
+    ("superq", 3008, 300, False, "f32"),      # fp32 P=2, whole super-batches only
+    ("superq", 3001, 300, False, "f64"),      # fp64 P=4
+    ("superq", 3001, 600, False, "f32"),      # fp32 P=4
+    ("superq", 2993, 600, False, "f64"),      # fp64 P=8
+    ("superq", 3000, 1000, False, "f32"),     # C2sq's width
+    ("superq", 17, 1000, False, "f64"),       # one super-batch + 1 row, fp64 P=8
+    ("aorr_hinge", 3000, 1000, True, "f32"),  # C3's width: d = 1001 with the intercept column (run_AoRR_ratio.py:40)
+    ("aorr_hinge", 2990, 1000, True, "f64"),
+    ("aorr_hinge", 3003, 200, False, "f32"),
+    ("aorr_hinge", 3003, 520, False, "f64"),
+    ("ehrm", 3000, 1000, False, "f32"),       # C4's width
+    ("ehrm", 3005, 1000, False, "f64"),
+    ("ehrm", 3000, 140, False, "f32"),
+    ("ehrm", 2999, 520, False, "f32"),
+    ("extremile_l1", 3001, 333, False, "f32"),  # padded columns (d % 4 != 0), lasso w-step
+]
+
+
+def _run_gpu(R, X, y, kw, storage, nit, no_fuse):
+    if no_fuse:
+        os.environ["RBL_NO_FUSE"] = "1"       # read by rbl_create
+    try:
+        s = R.ADMMmethod(X, y, max_iter=nit, tol=0.0, storage=storage, **kw)._s
+    finally:
+        os.environ.pop("RBL_NO_FUSE", None)
+    hist, fv = [], 0
+    for _ in range(nit):
+        st = s.step(True)
+        hist.append((st.primal, st.dual, st.rho, st.objective, st.ehrm_branch))
+        fv += st.fused_v
+    return np.array(hist), s.get_state(), fv
+
+
+@pytest.mark.parametrize("fam,n,d,intercept,storage", WIDTHS,
+                         ids=[f"{c[0]}-{c[1]}x{c[2] + (1 if c[3] else 0)}-{c[4]}" for c in WIDTHS])
+def test_rank_weighted_iterates_at_bench_widths(R, fam, n, d, intercept, storage):
+    from oracle import problems, admm
+    kw = FAM[fam]
+    X, y = problems.make_problem(n, d, seed=1000 + d + n, intercept=intercept)
+    if storage == "f32":
+        X = X.astype(np.float32).astype(np.float64)     # what the device stores: the oracle sees the same D
+    nit = 8
+    ref = admm.admm_solve(X, y, max_iter=nit, mode="exact", tol=0.0, **kw)
+    tol = 1e-9 if kw["loss"] == "binary_cross_entropy" else 1e-7     # hinge: the kinks amplify rounding
+    hf, sf, nfv = _run_gpu(R, X, y, kw, storage, nit, no_fuse=False)
+    hu, su, nuv = _run_gpu(R, X, y, kw, storage, nit, no_fuse=True)
+    assert nfv == nit and nuv == 0          # the v-only single-sweep kernel really ran / really did not
+    for name, h, st in (("fused", hf, sf), ("unfused", hu, su)):
+        assert np.allclose(h[:, 2], ref.rho, rtol=1e-15), name
+        assert np.allclose(h[:, 0], ref.primal, rtol=tol, atol=tol), (name, h[:, 0], ref.primal)
+        assert np.allclose(h[:, 1], ref.dual, rtol=tol, atol=tol), name
+        assert np.allclose(h[:, 3], ref.objective[1:], rtol=tol, atol=tol), name
+        if fam == "ehrm":
+            assert [int(b) for b in h[:, 4]] == [0 if b == "a" else 1 for b in ref.branch], name
+        assert np.max(np.abs(st["w"] - ref.w)) <= tol * max(1.0, np.max(np.abs(ref.w))), name
+        assert np.max(np.abs(st["z"] - ref.z)) <= 10 * tol * max(1.0, np.max(np.abs(ref.z))), name
+        assert np.max(np.abs(st["lam"] - ref.lam)) <= 10 * tol * max(1e-3, np.max(np.abs(ref.lam))), name
+    # the two device paths differ only in the order of the fp64 sums of one row
+    assert np.max(np.abs(sf["lam"] - su["lam"])) <= 1e-11 * max(1e-3, np.max(np.abs(su["lam"])))
+    assert np.max(np.abs(sf["w"] - su["w"])) <= 1e-11 * max(1.0, np.max(np.abs(su["w"])))
+
+
+# ------------------------------------------------------------------------------ C5's width
+def test_gram_at_c5_width(R):
+    """G = D^T D (gram.hip, fp64 MFMA) at d = 10 000 (C5) and at d = 4097 (tile tails in both directions)"""
+    L = R._lib
+    rng = np.random.default_rng(5)
+    for n, d, storage in ((300, 10000, "f32"), (2000, 4097, "f32"), (301, 4100, "f64")):
+        D = rng.standard_normal((n, d))
+        if storage == "f32":
+            D = D.astype(np.float32).astype(np.float64)
+        G = L.k_gram(D, storage)
+        ref = D.T @ D
+        # fp64 accumulation of n products of O(1) numbers: rounding ~ n * eps * |a||b|
+        assert np.max(np.abs(G - ref)) <= 1e-12 * n, (n, d, storage, np.max(np.abs(G - ref)))
+        assert np.array_equal(G, G.T)
+
+
+def test_lasso_wstep_at_c5_width(R):
+    """the Gram-space lasso at d = 10 000 (an 800 MB G) with a planted sparse solution: KKT residual of
+    min 1/2 w^T G w - q^T w + kappa |w|_1 below 1e-9 relative, support recovered"""
+    L = R._lib
+    rng = np.random.default_rng(6)
+    n, d = 1200, 10000
+    D = rng.standard_normal((n, d)) / np.sqrt(n)
+    G = D.T @ D
+    w_true = np.zeros(d)
+    supp = rng.choice(d, size=12, replace=False)
+    w_true[supp] = rng.choice([-1.0, 1.0], size=12) * (1.0 + rng.random(12))
+    q = G @ w_true
+    rho, reg = 1.0, 0.02          # kappa = reg / (2 rho) = 0.01
+    kappa = reg / (2 * rho)
+    w, iters = L.k_wstep(1, G, q, rho, reg, w0=np.zeros(d))
+    g = G @ w - q
+    on = w != 0
+    assert np.max(np.abs(g[on] + kappa * np.sign(w[on]))) <= 1e-9 * max(1.0, np.max(np.abs(q)))
+    assert np.max(np.abs(g[~on])) <= kappa * (1 + 1e-9)
+    assert set(np.flatnonzero(np.abs(w) > 0.5)) == set(supp)
+    assert np.count_nonzero(on) < 200
+
+
+@pytest.mark.parametrize("n,d,storage,kw", [
+    (200, 10000, "f32", dict(weight_function="erm", loss="binary_cross_entropy", l1_reg=0.01)),     # C5
+    (300, 4100, "f64", dict(weight_function="erm", loss="hinge", l2_reg=0.01)),
+    (200, 10000, "f32", dict(weight_function="superquantile", loss="binary_cross_entropy", l2_reg=0.01, args=[0.5])),
+], ids=["c5_erm_bce_l1_200x10000", "erm_hinge_l2_300x4100", "c5_variant_superq_200x10000"])
+def test_iterates_at_c5_width_vs_oracle(R, n, d, storage, kw):
+    """whole iterations at C5's width against the oracle (d = 10 000 was only ever compared with
+    the library itself).  erm takes the workgroup-per-row single-sweep kernel, the rank-weighted variant the
+    plain k_gemv / k_gemvt sweeps (the v-only kernel stops at 256 packets per row)."""
+    from oracle import problems, admm
+    X, y = problems.make_problem(n, d, seed=4242 + d)
+    if storage == "f32":
+        X = X.astype(np.float32).astype(np.float64)
+    nit = 10
+    ref = admm.admm_solve(X, y, max_iter=nit, mode="exact", tol=0.0, **kw)
+    s = R.ADMMmethod(X, y, max_iter=nit, tol=0.0, storage=storage, **kw)._s
+    tol = 1e-9 if kw["loss"] == "binary_cross_entropy" else 1e-7
+    fused = 0
+    for i in range(nit):
+        st = s.step(True)
+        fused += st.fused
+        assert abs(st.rho - ref.rho[i]) <= 1e-15 * ref.rho[i]
+        assert abs(st.primal - ref.primal[i]) <= tol * max(1.0, ref.primal[i]), (i, st.primal, ref.primal[i])
+        assert abs(st.dual - ref.dual[i]) <= tol * max(1.0, ref.dual[i]), i
+        assert abs(st.objective - ref.objective[i + 1]) <= tol * max(1.0, abs(ref.objective[i + 1])), i
+    if kw["weight_function"] == "erm":
+        assert fused == nit
+    state = s.get_state()
+    assert np.max(np.abs(state["w"] - ref.w)) <= tol * max(1.0, np.max(np.abs(ref.w)))
+    assert np.max(np.abs(state["z"] - ref.z)) <= 10 * tol * max(1.0, np.max(np.abs(ref.z)))
