@@ -71,9 +71,12 @@ def test_two_ranks_one_gpu_match_single_handle(cfg, tmp_path):
 
 
 MORE = [
-    (4, dict(n=30001, d=33, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=6)),
-    (3, dict(n=25000, d=21, wf="aorr", args=[0.2, 0.8], loss="hinge", reg=1e-4, wstep=2, iters=6)),
-    (4, dict(n=20000, d=21, wf="ehrm", B=-5.0, loss="binary_cross_entropy", reg=0.01, wstep=2, iters=5)),
+    # oracle=True: the CPU oracle runs on the device-generated rows (get_D() / labels()) - the sub-sampled
+    # parity of SURVEY 8c for generator data
+    (4, dict(n=30001, d=33, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=6,
+             oracle=True)),
+    (3, dict(n=25000, d=21, wf="aorr", args=[0.2, 0.8], loss="hinge", reg=1e-4, wstep=2, iters=6, oracle=True)),
+    (4, dict(n=20000, d=21, wf="ehrm", B=-5.0, loss="binary_cross_entropy", reg=0.01, wstep=2, iters=5, oracle=True)),
     (2, dict(n=30001, d=33, wf="extremile", args=[2.0], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=5,
              dist_z=False)),
 ]

@@ -124,5 +124,10 @@ def test_run_srm_rows():
     # here: 86 entries for 86 oracle iterations; fp32 storage of D may move the stop by one iteration
     assert abs(len(rows[0]) - ref.iters) <= 1
     assert abs(rows[0][-1] - ref.final_objective) <= 1e-6 * abs(ref.final_objective)
-    assert abs(rows[3][-1] - ref.final_objective) <= 2e-3 * abs(ref.final_objective)   # sADMM: smoothed w-step, same optimum
+    # sADMM (run_SRM.py:45-50) against the oracle's exact mode with the smoothed w-step and the t schedule
+    ref_s = admm.admm_solve(Xtr, ytr, "erm", "binary_cross_entropy", l1_reg=0.01, max_iter=200, mode="exact", tol=1e-4,
+                            smooth=True, t=1.0)
+    assert abs(len(rows[3]) - ref_s.iters) <= 1
+    assert abs(rows[3][-1] - ref_s.objective[-1]) <= 2e-6 * abs(ref_s.objective[-1])
+    assert abs(rows[3][-1] - ref.final_objective) <= 2e-3 * abs(ref.final_objective)   # and near the ADMM optimum
     assert 0.5 < rows[2][0] <= 1.0 and 0.5 < rows[5][0] <= 1.0

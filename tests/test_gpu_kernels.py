@@ -314,3 +314,26 @@ def test_weights_golden_g8(L):
         L.k_weights("nope", 10, [1])
     with pytest.raises(ValueError, match="need args"):
         L.k_weights("aorr_dc", 10, [2, 5])
+
+
+# ------------------------------------------------------------------- synthetic generator
+@pytest.mark.parametrize("n,d,storage", [(1000, 37, "f64"), (1000, 1000, "f32"), (3001, 6, "f64"), (257, 3, "f32")])
+def test_synthetic_generator_vs_numpy_restatement(n, d, storage):
+    """k_synth + column statistics + standardisation (synth.hip, sweep.hip, api.hip: rbl_synth_*) against
+    oracle/synth.py: labels, flips, cluster draws and special-column positions bit for bit (integer Philox
+    work); matrix values to 2e-5 (the device's __logf / __sincosf fast intrinsics against NumPy's float32
+    log / sin / cos), through the whole pipeline D = -y * (x - mean) / std."""
+    import admm_for_rank_based_loss_amd as rbl
+    from oracle import synth
+    s = rbl.Solver(n, d, "erm", "binary_cross_entropy", reg=0.01, wstep=2, storage=storage)
+    s.generate_synthetic(seed=17)
+    D, y = s.get_D(), s.labels()
+    Dn, yn = synth.standardized_D(17, d, n, storage=storage)
+    assert np.array_equal(y, yn)
+    assert np.max(np.abs(D - Dn)) <= 2e-5 * max(1.0, np.max(np.abs(Dn))), float(np.max(np.abs(D - Dn)))
+    # a shard of a larger problem regenerates the same raw rows: labels of rows [off, off + n) of a 4n-row problem
+    s2 = rbl.Solver(n, d, "erm", "binary_cross_entropy", reg=0.01, wstep=2, storage=storage, n_total=4 * n,
+                    row_offset=n + 3)
+    s2.synth_local(seed=17)
+    _, y2 = synth.raw_rows(17, d, n + 3, 2 * n + 3)
+    assert np.array_equal(s2.labels(), y2)

@@ -66,6 +66,39 @@ def test_iterates_match_oracle_exact(R, name, kw):
     assert np.max(np.abs(state["lam"] - ref.lam)) <= 10 * tol * max(1e-3, np.max(np.abs(ref.lam)))
 
 
+@pytest.mark.parametrize("n,d,t0", [(1500, 24, 1.0), (3000, 160, 1.0), (2000, 60, 0.05)],
+                         ids=["1500x24", "3000x160_single_sweep", "2000x60_t0.05"])
+def test_sadmm_iterates_match_oracle_exact(R, n, d, t0):
+    """smoothADMMmethod (algorithms.py:224-260) iteration by iteration against the oracle's exact mode with
+    smooth=True: the Huber-smoothed w-step (w_LBFGS.py:11-28) solved to ~1e-13 on both sides (device:
+    preconditioned nonlinear CG with exact line search, oracle: FISTA to 1e-14), the t schedule of
+    :254-255 (from iteration 17 on) and the final soft-threshold of :257-258.  1e-8 on every logged
+    quantity, t to rounding."""
+    from oracle import problems, admm
+    X, y = problems.make_problem(n, d, seed=31 + d)
+    nit = 45
+    kw = dict(weight_function="erm", loss="binary_cross_entropy", l1_reg=0.01)
+    ref = admm.admm_solve(X, y, max_iter=nit, mode="exact", tol=0.0, smooth=True, t=t0, **kw)
+    s = R.smoothADMMmethod(X, y, max_iter=nit, tol=0.0, storage="f64", t=t0, **kw)
+    inner = []
+    for i in range(nit):
+        st = s._s.step(want_objective=True)
+        inner.append(st.inner_iters)
+        assert abs(st.rho - ref.rho[i]) <= 1e-15 * ref.rho[i]
+        assert abs(st.primal - ref.primal[i]) <= 1e-8 * max(1.0, ref.primal[i]), (i, st.primal, ref.primal[i])
+        assert abs(st.dual - ref.dual[i]) <= 1e-8 * max(1.0, ref.dual[i]), (i, st.dual, ref.dual[i])
+        assert abs(st.objective - ref.objective[i + 1]) <= 1e-8 * max(1.0, abs(ref.objective[i + 1])), i
+    assert abs(s.t - ref.t) <= 1e-12 * ref.t                        # the t schedule, :254-255
+    assert max(inner) <= 200, inner                                 # the nonlinear CG, not its FISTA fallback
+    state = s._s.get_state()
+    s._s.finalize_smooth()                                          # :257-258
+    w_final = s._s.get_state()["w"]
+    assert np.max(np.abs(w_final - ref.w)) <= 1e-8 * max(1.0, np.max(np.abs(ref.w)))
+    assert np.count_nonzero(w_final) == np.count_nonzero(ref.w)
+    assert np.max(np.abs(state["z"] - ref.z)) <= 1e-7 * max(1.0, np.max(np.abs(ref.z)))
+    assert np.max(np.abs(state["lam"] - ref.lam)) <= 1e-7 * max(1e-3, np.max(np.abs(ref.lam)))
+
+
 def test_f32_storage_close_to_f64(R):
     """fp32 storage of D perturbs every entry by <= 6e-8 relative: the final objective
     moves by far less than the 1e-6 contract."""
@@ -118,8 +151,9 @@ def test_reference_trajectory_goldens(R, name, storage):
     converged_ref = bool(g["converged"])
     print(f"{name} [{storage}]: F_gpu={f_gpu:.12g} F_ref={f_ref:.12g} rel={rel:+.2e} iters gpu={len(s.train_losses)-1} ref={int(g['iters'])}")
     if name == "sadmm_erm_bce_l1":
-        # the smoothed problem's own optimum: both within the smoothing error of each other
-        assert abs(rel) <= 2e-3
+        # the reference's L-BFGS w-step is loose: the exact smoothed w-step ends within 5e-6 of it
+        # (the CPU oracle's exact mode does the same, tests/test_oracle_trajectories.py) and never above it
+        assert abs(rel) <= 5e-6 and rel <= 1e-9
     elif name.startswith("aorr_hinge"):
         assert f_gpu <= f_ref * (1 + 1e-6) + 1e-12     # non-convex + reference artifact: one-sided
     elif converged_ref:
@@ -131,6 +165,33 @@ def test_reference_trajectory_goldens(R, name, storage):
     else:
         # the reference did not reach its stop rule in max_iter: compare one-sidedly
         assert f_gpu <= f_ref * (1 + 1e-5) + 1e-12
+
+
+@pytest.mark.parametrize("name", ["aorr_bce_l2", "aorr_hinge_l2", "ehrm_bce_l2", "superq_bce_l2", "erm_bce_l1"])
+def test_f32_storage_contract_whole_solves(R, name):
+    """The fp32-storage contract (the shipped default, and what C2 / C3 / C4 are benched in): storing D = -y X in
+    fp32 is EXACT fp64 arithmetic on a matrix whose entries moved by <= 6e-8 relative (iterates vs the oracle
+    on the rounded matrix: tests/test_gpu_widths.py, 1e-9).  Whole solves of the golden configurations -
+    including the non-convex AoRR / EHRM families, whose trajectories amplify the perturbation along the way
+    (tests/stress_vs_oracle.py RAW=1: up to 5e-2 on intermediate residuals) - end within 1e-6 relative of
+    the fp64-storage solve (measured round 2: 5e-9 aorr, 2e-7 ehrm, 1e-9 convex) after the same number of
+    iterations +- 1."""
+    from oracle import problems
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"g9_{name}.npz"), allow_pickle=False)
+    cfg = json.loads(str(g["config"]))
+    X, y = problems.make_problem(cfg["n"], cfg["d"] - 1 if cfg["intercept"] else cfg["d"], cfg["seed"],
+                                 intercept=cfg["intercept"])
+    out = {}
+    for storage in ("f64", "f32"):
+        s = R.ADMMmethod(X, y, max_iter=cfg["max_iter"], storage=storage, **cfg["kw"])
+        s.start_store(X, y, **{k: v for k, v in cfg["kw"].items() if k != "B"})
+        w = _quiet(s.main_loop, verbose=False)
+        out[storage] = (s.objective.get_arrogate_loss(w), len(s.train_losses), w)
+    (f64, n64, w64), (f32, n32, w32) = out["f64"], out["f32"]
+    assert abs(f32 - f64) <= 1e-6 * abs(f64), (name, f32, f64)
+    assert abs(n32 - n64) <= 1, (n32, n64)
+    assert np.max(np.abs(w32 - w64)) <= 1e-4 * max(1.0, np.max(np.abs(w64)))
 
 
 def test_c1_published_config(R):

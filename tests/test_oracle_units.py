@@ -303,3 +303,35 @@ def test_zdist_rank_tree_and_rounds():
         u = np.concatenate([c.u for c in chunks])
         ref = pav.pav_exact(loss, sigma, rho, m)[0] if n else np.zeros(0)
         assert np.max(np.abs(u - ref), initial=0.0) <= 1e-10 * max(1.0, np.max(np.abs(ref), initial=0.0)), (trial, n, P, K)
+
+
+# --------------------------------------------------------------- synthetic generator (oracle/synth.py)
+def test_philox_known_answers_and_generator_restatement():
+    """The NumPy restatement of the device generator: Philox4x32-10 against the published Random123
+    known-answer vectors (kat_vectors: philox4x32 10), slices regenerate independently of the range
+    asked for (counter based), labels are balanced with ~1 % flips, columns are standardised with D = -y X
+    (load_data.py:101-116 statistics, algorithms.py:23)."""
+    from oracle import synth
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = synth.philox4x32_10(*[np.array([c], dtype=np.uint64) for c in ctr], *key)
+        assert tuple(int(g[0]) for g in got) == want
+    X, y = synth.raw_rows(17, 37, 0, 5000)
+    Xs, ys = synth.raw_rows(17, 37, 1234, 1300)
+    assert np.array_equal(X[1234:1300], Xs) and np.array_equal(y[1234:1300], ys)
+    assert X.dtype == np.float32 and set(np.unique(y)) == {-1.0, 1.0} and abs(np.mean(y)) < 0.05
+    special, mix = synth.special_columns(17, 37)
+    assert len(set(special)) == 4 and all(0 <= c < 37 for c in special)
+    noise = [j for j in range(37) if j not in special]
+    assert np.max(np.abs(X[:, noise].mean(axis=0))) < 0.06 and np.max(np.abs(X[:, noise].std(axis=0) - 1)) < 0.05
+    # redundant columns are exact linear combinations of the informative ones (make_classification's n_redundant)
+    f0, f1 = X[:, special[0]].astype(np.float64), X[:, special[1]].astype(np.float64)
+    assert np.max(np.abs(X[:, special[2]] - (f0 * mix[0] + f1 * mix[2]))) < 1e-5
+    D, yd = synth.standardized_D(17, 37, 5000)
+    Xstd = -yd[:, None] * D
+    assert np.max(np.abs(Xstd.mean(axis=0))) < 1e-12 and np.max(np.abs(Xstd.std(axis=0) - 1)) < 1e-12
+    # the class-separating column carries the label: a linear classifier on it beats 70 %
+    assert np.mean(np.sign(Xstd[:, special[0]]) == yd) > 0.7
