@@ -18,7 +18,7 @@ WSTEP_L1, WSTEP_L2, WSTEP_SMOOTH_L1 = 1, 2, 3
 STORAGE = {"f32": 0, "float32": 0, "f64": 1, "float64": 1}
 BUF_M, BUF_Q, BUF_RED, BUF_G, BUF_V, BUF_Z, BUF_LAM, BUF_W, BUF_COLSTATS = range(9)
 (BUF_ZD_SKEYS, BUF_ZD_SIDS, BUF_ZD_RKEYS, BUF_ZD_RIDS, BUF_ZD_SMALL, BUF_ZD_BIDS, BUF_ZD_BU, BUF_ZD_ZIDS,
- BUF_ZD_ZU) = range(16, 25)
+ BUF_ZD_ZU, BUF_ZD_COUNTS) = range(16, 26)
 KERNEL_GEMV, KERNEL_GEMVT, KERNEL_SWEEP_ERM = 0, 1, 2
 
 

@@ -255,10 +255,11 @@ class Solver:
     def zd_sort_local(self, nsamples):
         _lib.check(self.lib.rbl_zd_sort_local(self._h, int(nsamples)))
 
-    def zd_partition(self, splitters_ptr, nparts):
-        out = (C.c_int64 * int(nparts))()
+    def zd_partition(self, splitters_ptr, nparts, to_host=False):
+        """counts per destination stay on the device (BUF_ZD_COUNTS); to_host=True also downloads them"""
+        out = (C.c_int64 * int(nparts))() if to_host else None
         _lib.check(self.lib.rbl_zd_partition(self._h, C.c_void_p(splitters_ptr), int(nparts), out))
-        return [int(x) for x in out]
+        return [int(x) for x in out] if to_host else None
 
     def zd_sort_losses(self, nsamples):
         _lib.check(self.lib.rbl_zd_sort_losses(self._h, int(nsamples)))
@@ -291,10 +292,10 @@ class Solver:
     def zd_seam_fill(self, sums_ptr):
         _lib.check(self.lib.rbl_zd_seam_fill(self._h, C.c_void_p(sums_ptr)))
 
-    def zd_return_partition(self, nmax, world):
-        out = (C.c_int64 * int(world))()
+    def zd_return_partition(self, nmax, world, to_host=False):
+        out = (C.c_int64 * int(world))() if to_host else None
         _lib.check(self.lib.rbl_zd_return_partition(self._h, int(nmax), int(world), out))
-        return [int(x) for x in out]
+        return [int(x) for x in out] if to_host else None
 
     def zd_scatter(self, n_back):
         _lib.check(self.lib.rbl_zd_scatter(self._h, int(n_back)))

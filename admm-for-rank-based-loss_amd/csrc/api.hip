@@ -80,6 +80,7 @@ struct rbl_solver {
     ZdSeam* zd_seam = nullptr;
     int* zd_err = nullptr;
     long long* zd_bounds_dev = nullptr;
+    long long* zd_counts_dev = nullptr;   // RBL_BUF_ZD_COUNTS: per-destination counts of the sample sort (64 x int64)
     u32* zd_zids = nullptr;          // row ids received back (n)
     double *zd_locx_a = nullptr, *zd_chunk_a = nullptr, *zd_cph_a = nullptr, *zd_cpl_a = nullptr;
     double *zd_locx_b = nullptr, *zd_chunk_b = nullptr, *zd_cph_b = nullptr, *zd_cpl_b = nullptr;
@@ -98,11 +99,15 @@ struct rbl_solver {
     bool phase_timing = false;   // rbl_profile_kernels level 2: HIP events around the phases (ms_* of rbl_stats)
     int64_t n_fused = 0, n_mispred = 0;
     bool fused_v_ran = false;
-    int n_sync = 0;        // host waits inside the iteration in flight (rbl_stats.host_syncs)
+    bool keys_ready = false;   // rbl_phase_m left the sort's input (keys of m, global row ids) in sw.keys[0] / vals[0]
     int sort_passes = 0;   // radix passes executed by the z-step in flight
 };
 
+static thread_local int g_host_syncs = 0;   // one solver handle per host thread (include/rbl.h)
+void rbl_note_host_sync() { ++g_host_syncs; }
+
 void rbl_spin_wait(const volatile int* word, int sentinel, hipStream_t stream) {
+    ++g_host_syncs;
     // No event behind the kernel: an event record costs ~5 us of stream time on this device and
     // the iteration has none left in its steady state.  A launch that failed never writes the
     // word, so after a generous spin the stream itself is waited for (then the word is final).
@@ -335,10 +340,11 @@ int ensure_v(rbl_solver* h) {
 int z_step_sorted(rbl_solver* h, const double* msrc, double rho) {
     hipStream_t s = h->stream;
     const int64_t nt = h->nt;
-    RBL_TRY(launch_keys_from_m(nt, msrc, h->sw.keys[0], h->sw.vals[0], s));
+    // rbl_phase_m already formed the keys with m when it covers the whole problem (one pass instead of two)
+    if (!(h->keys_ready && msrc == h->m && nt == h->n)) RBL_TRY(launch_keys_from_m(nt, msrc, h->sw.keys[0], h->sw.vals[0], s));
+    h->keys_ready = false;   // the sort consumes its input
     RBL_TRY(launch_radix_sort(h->sw, nt, true, s));
-    RBL_TRY(launch_unflip_keys(nt, h->sw.keys[0], h->pw.ms, s));
-    RBL_TRY(launch_prefix(h->pw.ms, nt, h->pw.locx_m, h->pw.chunk_m, h->pw.cph_m, h->pw.cpl_m, s));
+    RBL_TRY(launch_unflip_prefix(h->sw.keys[0], nt, h->pw.ms, h->pw.locx_m, h->pw.chunk_m, h->pw.cph_m, h->pw.cpl_m, s));
     const bool ehrm = h->cfg.weight_function == RBL_W_EHRM;
     // EHRM: the branch test solves both element prox problems; they are level 0 of the tree as well
     double* u0a = ehrm ? h->pw.u : nullptr;
@@ -358,6 +364,7 @@ int risk_from_v(rbl_solver* h, const double* v_all, double* out_dev) {
     hipStream_t s = h->stream;
     if (h->cfg.weight_function == RBL_W_ERM)
         return launch_loss_sum(h->cfg.loss, h->nt, v_all, 1.0 / (double)h->nt, h->partials, out_dev, s);
+    h->keys_ready = false;   // the sort workspace is reused: keys left by rbl_phase_m are gone
     RBL_TRY(launch_loss_keys(h->nt, v_all, h->sw.keys[0], s));
     RBL_TRY(launch_radix_sort(h->sw, h->nt, false, s));
     return launch_sorted_loss_dot(h->cfg.loss, h->nt, h->sw.keys[0], h->sigma_a, h->partials, out_dev, s);
@@ -391,7 +398,7 @@ int rbl_destroy(rbl_solver* h) {
     if (h->red_owned) dev_free(h->red);
     dev_free(h->red2); dev_free(h->ysign); dev_free(h->colstats); dev_free(h->z_next); dev_free(h->p); dev_free(h->p_alt); dev_free(h->pred);
     if (h->hstat) (void)hipHostFree(h->hstat);
-    dev_free(h->zd_small); dev_free(h->zd_seam); dev_free(h->zd_err); dev_free(h->zd_bounds_dev); dev_free(h->zd_zids);
+    dev_free(h->zd_small); dev_free(h->zd_seam); dev_free(h->zd_err); dev_free(h->zd_bounds_dev); dev_free(h->zd_counts_dev); dev_free(h->zd_zids);
     dev_free(h->zd_locx_a); dev_free(h->zd_chunk_a); dev_free(h->zd_cph_a); dev_free(h->zd_cpl_a);
     dev_free(h->zd_locx_b); dev_free(h->zd_chunk_b); dev_free(h->zd_cph_b); dev_free(h->zd_cpl_b);
     free_sort(h->sw);
@@ -893,7 +900,13 @@ int rbl_phase_m(rbl_solver* h) {
     if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[0], h->stream));
     if (h->fused_ok && h->z_ready) return RBL_OK;
     RBL_TRY(ensure_v(h));
-    if (h->sorted_path) RBL_TRY(launch_make_m(h->n, h->step_rho, h->v, h->lam, h->m, h->stream));
+    if (h->sorted_path) {
+        // m = D w - lambda/rho (algorithms.py:89) and, in the same pass, the sort's input for the z-step: keys of
+        // m with the GLOBAL row id as payload (single GPU: off = 0; sharded: what rbl_zd_sort_local sorts)
+        RBL_TRY(launch_make_m_keys(h->n, h->step_rho, h->v, h->lam, h->m, h->sw.keys[0], h->sw.vals[0], (u32)h->off,
+                                   h->stream));
+        h->keys_ready = true;
+    }
     return RBL_OK;
 }
 
@@ -1055,8 +1068,14 @@ int rbl_phase_dual(rbl_solver* h, int want_objective) {
 // single stream wait and no copies (each small device-to-host copy costs ~15 us of stream time).
 static __global__ void k_pack_stats(const double* __restrict__ red, const double* __restrict__ red2,
                              const double* __restrict__ pred, const int* __restrict__ branch,
-                             const unsigned* __restrict__ counters, double* __restrict__ hstat, int seq) {
+                             const unsigned* __restrict__ counters, int* __restrict__ zd_err,
+                             double* __restrict__ hstat, int seq) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    hstat[9] = 0.0;
+    if (zd_err) {          // distributed z-step: a seam search that ran out of rounds (reported, then cleared)
+        hstat[9] = (double)zd_err[0];
+        zd_err[0] = 0;
+    }
     hstat[0] = red[0];
     hstat[1] = red[1];
     hstat[2] = red2[0];
@@ -1082,7 +1101,7 @@ int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
     hipLaunchKernelGGL(k_pack_stats, dim3(1), dim3(64), 0, h->stream, h->red, h->red2,
                        h->fused_ran ? h->pred : (const double*)nullptr,
                        (h->sorted_path && h->cfg.weight_function == RBL_W_EHRM) ? h->pw.branch : (const int*)nullptr,
-                       h->sorted_path ? h->pw.counters : (const unsigned*)nullptr, h->hstat, pack_seq);
+                       h->sorted_path ? h->pw.counters : (const unsigned*)nullptr, h->zd_err, h->hstat, pack_seq);
     RBL_HIP(hipGetLastError());
     // Single-sweep lasso iterations: everything the next w-step needs is on the device already
     // (q from the pass, rho_{k+1} = pred[0]), so it is enqueued now and runs while the host waits
@@ -1112,6 +1131,10 @@ int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
     const double r[2] = {hs[0], hs[1]}, r2[3] = {hs[2], hs[3], hs[4]}, pr[2] = {hs[5], hs[6]};
     const int br = (int)hs[7];
     const unsigned merges = (unsigned)hs[8];
+    if (hs[9] != 0.0) {
+        rbl_set_error("distributed z-step: a seam search did not finish within its rounds");
+        return RBL_ERR_STATE;
+    }
     const double primal = std::sqrt(r[0] > 0.0 ? r[0] : 0.0);   // algorithms.py:135
     const double dual = std::sqrt(r2[0] > 0.0 ? r2[0] : 0.0);   // algorithms.py:136
     double objective = NAN;
@@ -1198,13 +1221,13 @@ int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
         out->fused = fused;
         out->mispredicted = mispred;
         out->fused_v = h->fused_v_ran ? 1 : 0;
-        out->host_syncs = h->n_sync + 1;   // + the wait for the statistics block above
+        out->host_syncs = g_host_syncs;    // stream waits, blocking copies and spins since the last rbl_phase_finish
         out->sort_passes = h->sorted_path ? h->sort_passes : -1;
         out->reserved = 0;
     }
     h->rho = rho_next;
     h->iter = i + 1;
-    h->n_sync = 0;
+    g_host_syncs = 0;
     h->sort_passes = 0;
     return RBL_OK;
 }
@@ -1327,6 +1350,7 @@ int zd_ensure(rbl_solver* h) {
     RBL_TRY(dev_alloc(&h->zd_seam, 1));
     RBL_TRY(dev_alloc(&h->zd_err, 1));
     RBL_TRY(dev_alloc(&h->zd_bounds_dev, 80));
+    RBL_TRY(dev_alloc(&h->zd_counts_dev, 64));
     RBL_TRY(dev_alloc(&h->zd_zids, (size_t)h->n));
     RBL_TRY(alloc_prefix(&h->zd_locx_a, &h->zd_chunk_a, &h->zd_cph_a, &h->zd_cpl_a, h->nt));
     h->zpa = Prefix{h->zd_locx_a, h->zd_cph_a, h->zd_cpl_a};
@@ -1349,8 +1373,11 @@ int rbl_zd_sort_local(rbl_solver* h, int nsamples) {
     }
     hipStream_t s = h->stream;
     // keys of the local m, payload = GLOBAL row id
-    RBL_TRY(launch_keys_from_m(h->n, h->m, h->sw.keys[0], h->sw.vals[0], s));
-    if (h->off != 0) RBL_TRY(launch_add_u32(h->n, h->sw.vals[0], (u32)h->off, s));
+    if (!h->keys_ready) {
+        RBL_TRY(launch_keys_from_m(h->n, h->m, h->sw.keys[0], h->sw.vals[0], s));
+        if (h->off != 0) RBL_TRY(launch_add_u32(h->n, h->sw.vals[0], (u32)h->off, s));
+    }
+    h->keys_ready = false;
     RBL_TRY(launch_radix_sort(h->sw, h->n, true, s));
     RBL_TRY(launch_zd_sample(h->sw.keys[0], h->n, nsamples, h->zd_small + ZD_OFF_SAMPLES, s));
     return RBL_OK;
@@ -1367,6 +1394,7 @@ int rbl_zd_sort_losses(rbl_solver* h, int nsamples) {
     }
     hipStream_t s = h->stream;
     RBL_TRY(ensure_v(h));
+    h->keys_ready = false;
     RBL_TRY(launch_loss_keys(h->n, h->v, h->sw.keys[0], s));
     RBL_TRY(launch_radix_sort(h->sw, h->n, false, s));
     RBL_TRY(launch_zd_sample(h->sw.keys[0], h->n, nsamples, h->zd_small + ZD_OFF_SAMPLES, s));
@@ -1395,22 +1423,22 @@ int rbl_zd_risk(rbl_solver* h, int64_t nrecv, int64_t sigma_off) {
 
 int rbl_zd_partition(rbl_solver* h, const void* splitters_dev, int nparts, int64_t* send_counts) {
     RBL_ENTER_ITER(h);
-    if (nparts < 1 || nparts > 64 || !send_counts) return RBL_ERR_INVALID;
-    long long hb[64];
-    if (nparts > 1) {
+    RBL_TRY(zd_ensure(h));
+    if (nparts < 1 || nparts > 64) return RBL_ERR_INVALID;
+    if (nparts > 1)
         RBL_TRY(launch_zd_split_bounds(h->sw.keys[0], h->n, (const double*)splitters_dev, nparts - 1, h->zd_bounds_dev,
                                        h->stream));
-        RBL_HIP(hipMemcpyAsync(hb, h->zd_bounds_dev, sizeof(long long) * (nparts - 1), hipMemcpyDeviceToHost, h->stream));
-    }
-    RBL_HIP(hipStreamSynchronize(h->stream));
-    long long prev = 0;
-    for (int j = 0; j < nparts; ++j) {
-        long long b = j == nparts - 1 ? (long long)h->n : hb[j];
-        if (b < prev) b = prev;   // splitters are sorted; equal splitters give empty parts
-        send_counts[j] = b - prev;
-        prev = b;
-    }
+    // the counts stay on the device (RBL_BUF_ZD_COUNTS): the driver all-gathers them there and reads the whole
+    // count matrix with ONE host wait; send_counts != NULL additionally downloads this rank's row
+    RBL_TRY(launch_zd_counts_from_bounds(h->zd_bounds_dev, nparts, h->n, h->zd_counts_dev, h->stream));
     h->zd_world = nparts;
+    if (send_counts) {
+        long long hc[64];
+        RBL_HIP(hipMemcpyAsync(hc, h->zd_counts_dev, sizeof(long long) * nparts, hipMemcpyDeviceToHost, h->stream));
+        RBL_HIP(hipStreamSynchronize(h->stream));
+        rbl_note_host_sync();
+        for (int j = 0; j < nparts; ++j) send_counts[j] = hc[j];
+    }
     return RBL_OK;
 }
 
@@ -1431,8 +1459,7 @@ int rbl_zd_prepare(rbl_solver* h, int64_t nrecv, int64_t sigma_off) {
     h->zd_n = nrecv;
     h->zd_off = sigma_off;
     RBL_TRY(launch_radix_sort(h->sw, nrecv, true, s));   // runs arrive in rank order: stable => ties in row order
-    RBL_TRY(launch_unflip_keys(nrecv, h->sw.keys[0], h->pw.ms, s));
-    RBL_TRY(launch_prefix(h->pw.ms, nrecv, h->pw.locx_m, h->pw.chunk_m, h->pw.cph_m, h->pw.cpl_m, s));
+    RBL_TRY(launch_unflip_prefix(h->sw.keys[0], nrecv, h->pw.ms, h->pw.locx_m, h->pw.chunk_m, h->pw.cph_m, h->pw.cpl_m, s));
     RBL_TRY(launch_prefix(h->sigma_a + sigma_off, nrecv, h->zd_locx_a, h->zd_chunk_a, h->zd_cph_a, h->zd_cpl_a, s));
     const bool ehrm = h->cfg.weight_function == RBL_W_EHRM;
     double* fv = h->zd_small + ZD_OFF_FV;
@@ -1506,19 +1533,24 @@ int rbl_zd_seam_fill(rbl_solver* h, const void* sums_total_dev) {
 // blocks of nmax); counts[r] = how many go back to rank r.  RBL_BUF_ZD_BIDS / BU hold them.
 int rbl_zd_return_partition(rbl_solver* h, int64_t nmax, int world, int64_t* counts) {
     RBL_ENTER_ITER(h);
-    if (world < 1 || world > 64 || nmax < 1 || !counts) return RBL_ERR_INVALID;
+    if (world < 1 || world > 64 || nmax < 1) return RBL_ERR_INVALID;
     hipStream_t s = h->stream;
-    int herr = 0;
     RBL_TRY(launch_zd_ids_to_keys(h->zd_n, h->sw.vals[0], h->sw.keys[0], h->sw.vals[0], s));
     int id_bits = 1;
     while (id_bits < 32 && (1LL << id_bits) < h->nt) ++id_bits;
     RBL_TRY(launch_radix_sort(h->sw, h->zd_n, true, s, id_bits));   // row ids < n_total: 4 passes up to 2^32 rows
-    RBL_TRY(launch_zd_owner_bounds(h->sw.keys[0], h->zd_n, nmax, world, h->zd_bounds_dev, s));
     RBL_TRY(launch_zd_gather_back(h->zd_n, h->sw.keys[0], h->sw.vals[0], h->pw.u, h->sw.vals[1], (double*)h->sw.keys[1], s));
+    // counts == NULL: no host wait.  How many rows go back to owner r is known to the driver already: it is what
+    // r sent to this chunk in the forward exchange (the count matrix of the return trip is the transpose);
+    // a seam search that did not finish is reported by rbl_phase_finish (the flag travels in the statistics block)
+    if (!counts) return RBL_OK;
+    int herr = 0;
+    RBL_TRY(launch_zd_owner_bounds(h->sw.keys[0], h->zd_n, nmax, world, h->zd_bounds_dev, s));
     long long hb[65];
     RBL_HIP(hipMemcpyAsync(hb, h->zd_bounds_dev, sizeof(long long) * (world + 1), hipMemcpyDeviceToHost, s));
     RBL_HIP(hipMemcpyAsync(&herr, h->zd_err, sizeof(int), hipMemcpyDeviceToHost, s));
     RBL_HIP(hipStreamSynchronize(s));
+    rbl_note_host_sync();
     if (herr) {
         RBL_HIP(hipMemsetAsync(h->zd_err, 0, sizeof(int), s));
         rbl_set_error("distributed z-step: a seam search did not finish within its rounds");
@@ -1566,6 +1598,7 @@ int rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles) {
         case RBL_BUF_ZD_BU: p = h->sorted_path ? h->sw.keys[1] : nullptr; cnt = h->nt; break;
         case RBL_BUF_ZD_ZIDS: RBL_TRY(zd_ensure(h)); p = h->zd_zids; cnt = h->n; break;
         case RBL_BUF_ZD_ZU: p = h->m; cnt = h->n; break;
+        case RBL_BUF_ZD_COUNTS: RBL_TRY(zd_ensure(h)); p = h->zd_counts_dev; cnt = 64; break;
         default: rbl_set_error("unknown buffer id %d", which); return RBL_ERR_INVALID;
     }
     if (dev_ptr) *dev_ptr = p;
@@ -1579,6 +1612,7 @@ int rbl_risk_from_v(rbl_solver* h, const void* v_all_dev, double* out) {
     RBL_TRY(risk_from_v(h, (const double*)v_all_dev, h->red2 + 4));
     RBL_HIP(hipMemcpyAsync(out, h->red2 + 4, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     RBL_HIP(hipStreamSynchronize(h->stream));
+    rbl_note_host_sync();
     return RBL_OK;
 }
 

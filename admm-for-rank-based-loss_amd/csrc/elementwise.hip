@@ -45,6 +45,17 @@ __global__ void k_make_m(long long n, double rho, const double* __restrict__ v, 
         m[i] = v[i] - lam[i] / rho;  // algorithms.py:89
 }
 
+__global__ void k_make_m_keys(long long n, double rho, const double* __restrict__ v, const double* __restrict__ lam,
+                              double* __restrict__ m, u64* __restrict__ keys, u32* __restrict__ idx, u32 idx_off) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const double x = v[i] - lam[i] / rho;  // algorithms.py:89
+        m[i] = x;
+        keys[i] = rbl::flip_key(x);
+        idx[i] = (u32)i + idx_off;
+    }
+}
+
 __global__ void k_keys_from_m(long long n, const double* __restrict__ m, u64* __restrict__ keys,
                               u32* __restrict__ idx) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -264,6 +275,14 @@ int launch_erm_zc(int loss, int64_t n, double sigma0, double rho, const double* 
 int launch_make_m(int64_t n, double rho, const double* v, const double* lam, double* m, hipStream_t s) {
     if (n <= 0) return RBL_OK;
     hipLaunchKernelGGL(k_make_m, dim3(ew_grid(n)), dim3(256), 0, s, (long long)n, rho, v, lam, m);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_make_m_keys(int64_t n, double rho, const double* v, const double* lam, double* m, u64* keys, u32* idx,
+                       u32 idx_off, hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    hipLaunchKernelGGL(k_make_m_keys, dim3(ew_grid(n)), dim3(256), 0, s, (long long)n, rho, v, lam, m, keys, idx, idx_off);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

@@ -34,14 +34,28 @@ inline unsigned pv_grid(long long n, int threads = PV_THREADS, long long cap = 1
 // ---------------------------------------------------------------- prefix sums
 // locx[i] = sum of x over [chunk_start(i), i); chunk_tot[c] = sum of chunk c.  One block
 // per 1024-chunk, 256 threads x 4 consecutive elements.  Positions 0..n inclusive.
+// KEYS: x is the sorted key array of the radix sort; the values are recovered on the fly (and stored
+// to ms_out: the sorted m) instead of by a streaming pass of their own
+template <bool KEYS>
 __global__ __launch_bounds__(256) void k_chunk_scan(const double* __restrict__ x, long long n,
-                                                     double* __restrict__ locx, double* __restrict__ chunk_tot) {
+                                                     double* __restrict__ locx, double* __restrict__ chunk_tot,
+                                                     double* __restrict__ ms_out) {
     __shared__ double wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long base = (long long)blockIdx.x * PAV_CHUNK + tid * 4;
     double a[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a[k] = (base + k < n) ? x[base + k] : 0.0;
+    for (int k = 0; k < 4; ++k) {
+        a[k] = 0.0;
+        if (base + k < n) {
+            if (KEYS) {
+                a[k] = rbl::unflip_key(reinterpret_cast<const u64*>(x)[base + k]);
+                ms_out[base + k] = a[k];
+            } else {
+                a[k] = x[base + k];
+            }
+        }
+    }
     double tsum = (a[0] + a[1]) + (a[2] + a[3]);
     double incl = tsum;
 #pragma unroll
@@ -697,6 +711,19 @@ __global__ void k_zd_split_bounds(const u64* __restrict__ keys, long long n, con
     bounds[j] = lo;
 }
 
+// split positions -> how many sorted rows go to each part (equal splitters give empty parts); stays on the device
+__global__ void k_zd_counts_from_bounds(const long long* __restrict__ bounds, int nparts, long long n,
+                                        long long* __restrict__ counts) {
+    if (threadIdx.x || blockIdx.x) return;
+    long long prev = 0;
+    for (int j = 0; j < nparts; ++j) {
+        long long b = (j == nparts - 1) ? n : bounds[j];
+        if (b < prev) b = prev;
+        counts[j] = b - prev;
+        prev = b;
+    }
+}
+
 __global__ void k_zd_bounds(const double* __restrict__ u, long long n, double* __restrict__ out3) {
     if (threadIdx.x || blockIdx.x) return;
     out3[0] = n > 0 ? u[0] : 0.0;
@@ -918,7 +945,19 @@ int64_t pav_num_recs(int64_t n) { return n / (2 * PB_TILE) + 2; }
 int launch_prefix(const double* x, int64_t n, double* locx, double* chunk_tot, double* cph, double* cpl,
                   hipStream_t s) {
     const long long nc = pav_num_chunks(n);
-    hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)nc), dim3(256), 0, s, x, (long long)n, locx, chunk_tot);
+    hipLaunchKernelGGL(k_chunk_scan<false>, dim3((unsigned)nc), dim3(256), 0, s, x, (long long)n, locx, chunk_tot,
+                       (double*)nullptr);
+    hipLaunchKernelGGL(k_chunk_prefix_dd, dim3(1), dim3(1024), 0, s, chunk_tot, nc, cph, cpl);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+// sorted keys -> sorted m (ms) and its two-level prefix sums in one pass
+int launch_unflip_prefix(const u64* keys, int64_t n, double* ms, double* locx, double* chunk_tot, double* cph, double* cpl,
+                         hipStream_t s) {
+    const long long nc = pav_num_chunks(n);
+    hipLaunchKernelGGL(k_chunk_scan<true>, dim3((unsigned)nc), dim3(256), 0, s, reinterpret_cast<const double*>(keys),
+                       (long long)n, locx, chunk_tot, ms);
     hipLaunchKernelGGL(k_chunk_prefix_dd, dim3(1), dim3(1024), 0, s, chunk_tot, nc, cph, cpl);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
@@ -1046,6 +1085,11 @@ int launch_zd_sample(const u64* keys, int64_t n, int ns, double* out, hipStream_
 int launch_zd_split_bounds(const u64* keys, int64_t n, const double* split, int nsplit, long long* bounds, hipStream_t s) {
     if (nsplit <= 0) return RBL_OK;
     hipLaunchKernelGGL(k_zd_split_bounds, dim3((nsplit + 63) / 64), dim3(64), 0, s, keys, (long long)n, split, nsplit, bounds);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zd_counts_from_bounds(const long long* bounds, int nparts, int64_t n, long long* counts, hipStream_t s) {
+    hipLaunchKernelGGL(k_zd_counts_from_bounds, dim3(1), dim3(64), 0, s, bounds, nparts, (long long)n, counts);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

@@ -11,6 +11,8 @@ void rbl_set_error(const char* fmt, ...);
 // spins on the word; after 2 s without a change the stream is waited for instead, so that a
 // failed launch cannot hang the host.
 void rbl_spin_wait(const volatile int* word, int sentinel, hipStream_t stream);
+// every host wait for the device inside an iteration is counted (rbl_stats.host_syncs); rbl_spin_wait counts itself
+void rbl_note_host_sync();
 
 #define RBL_HIP(x)                                                                         \
     do {                                                                                   \
@@ -72,6 +74,9 @@ int launch_standardize_negy(int storage, void* D, int64_t n, int64_t ld, int64_t
 int launch_erm_zc(int loss, int64_t n, double sigma0, double rho, const double* v, const double* lam,
                   double* m, double* z, double* c, hipStream_t s);
 int launch_make_m(int64_t n, double rho, const double* v, const double* lam, double* m, hipStream_t s);
+// m = v - lambda/rho together with the sort's input: keys[i] = order-preserving transform of m[i], idx[i] = i + idx_off
+int launch_make_m_keys(int64_t n, double rho, const double* v, const double* lam, double* m, u64* keys, u32* idx,
+                       u32 idx_off, hipStream_t s);
 int launch_keys_from_m(int64_t n, const double* m, u64* keys, u32* idx, hipStream_t s);
 int launch_prox(int loss, int64_t n, const double* sigma, double rho, const double* m, double* out,
                 hipStream_t s);
@@ -124,6 +129,8 @@ int64_t pav_num_recs(int64_t n);
 int launch_prefix(const double* x, int64_t n, double* locx, double* chunk_tot, double* cph, double* cpl,
                   hipStream_t s);
 int launch_unflip_keys(int64_t n, const u64* keys, double* ms, hipStream_t s);
+int launch_unflip_prefix(const u64* keys, int64_t n, double* ms, double* locx, double* chunk_tot, double* cph, double* cpl,
+                         hipStream_t s);
 // EHRM: scalar branch test (PAV_cpt.py:205-226) -> *branch
 // u0a / u0b (optional): the element prox of both branches is kept for launch_pav_tree
 int launch_ehrm_branch(int64_t n, const double* sa, const double* sb, double B, double rho, const double* ms,
@@ -149,6 +156,7 @@ int launch_add_u32(int64_t n, u32* x, u32 add, hipStream_t s);
 int launch_make_c(int64_t n, const double* z, const double* lam, double rho, double* c, hipStream_t s);
 int launch_zd_sample(const u64* keys, int64_t n, int ns, double* out, hipStream_t s);
 int launch_zd_split_bounds(const u64* keys, int64_t n, const double* split, int nsplit, long long* bounds, hipStream_t s);
+int launch_zd_counts_from_bounds(const long long* bounds, int nparts, int64_t n, long long* counts, hipStream_t s);
 int launch_zd_bounds(const double* u, int64_t n, double* out3, hipStream_t s);
 int launch_zd_seam_setup(int rank, int world, int level, const double* bounds_all, int64_t n, ZdSeam* st, hipStream_t s);
 int launch_zd_update_propose(int loss, ZdSeam* st, const double* u, int K, int world, const double* cand_prev,

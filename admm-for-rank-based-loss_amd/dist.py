@@ -16,6 +16,11 @@ of v, m, z, lambda; w, G, sigma are replicated.  Per iteration:
   4. replicated d-space w-step                                     (engine.phase_w)
   5. local  v = D w, lambda update, partial sums; all-reduce(sum) of 2 doubles
                                                                    (phase_dual/finish)
+Host waits and collectives are counted per iteration (``collectives`` / ``driver_syncs`` on the returned
+statistics, next to the library's own ``host_syncs``): the distributed z-step needs ONE host wait for the
+count matrix of its forward exchange (the split sizes of an all-to-all are host arguments; the return trip's
+matrix is its transpose), one for the rank bounds the merge tree looks at, and one more per tree level that
+really has to pool across a rank boundary - levels whose seams are all in order issue no collective at all.
 One-time: all-reduce of the local Gram matrices (d*d doubles) and, for generated data, of
 the column sums.  The engine is any object with the phase methods below; ``GpuEngine``
 binds them to librbl.so, the CPU tests plug in a NumPy engine built on the oracle.
@@ -50,6 +55,7 @@ class GpuEngine:
         self.device = torch.device("cuda", device)
         self.n_local, self.n_total, self.d = solver.n, solver.n_total, solver.d
         self.sorted_path = solver.cfg.weight_function != 0
+        self.needs_branch_sum = solver.cfg.weight_function == 6      # EHRM: two scalars summed over the ranks
         self._views = {}
         torch.cuda.set_device(self.device)
         # library kernels and torch collectives are ordered on one stream
@@ -125,8 +131,11 @@ class GpuEngine:
         return self._small(0, nsamples)
 
     def zd_partition(self, splitters):
+        """per-destination counts of the local sorted run, left on the device (int64 x world)"""
+        from . import _lib
         self._zd_world = splitters.numel() + 1
-        return self.s.zd_partition(splitters.data_ptr(), self._zd_world)
+        self.s.zd_partition(splitters.data_ptr(), self._zd_world)
+        return self._zdv(_lib.BUF_ZD_COUNTS, "<i8")[: self._zd_world]
 
     def zd_sort_losses(self, nsamples):
         self.s.zd_sort_losses(nsamples)
@@ -178,7 +187,7 @@ class GpuEngine:
         self.s.zd_seam_fill(sums_total.data_ptr())
 
     def zd_return_partition(self, nmax, world):
-        return self.s.zd_return_partition(nmax, world)
+        self.s.zd_return_partition(nmax, world)      # no host wait: the driver knows the counts (transpose)
 
     def zd_back_send(self):
         from . import _lib
@@ -216,9 +225,12 @@ class ShardedADMM:
         # a 1-rank group normally skips its (identity) all-reduces; bench.py --sharded-driver sets this
         # to issue them anyway and time the collective's launch path on a 1-GPU box
         self.always_allreduce = False
+        self.n_coll = 0      # collectives issued in the iteration in flight
+        self.n_sync = 0      # host waits of this driver in the iteration in flight (device -> host reads)
 
     def _allreduce(self, t):
         if (self.world > 1 or self.always_allreduce) and t.numel() > 0:
+            self.n_coll += 1
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def _allgather_rows(self, local):
@@ -232,24 +244,35 @@ class ShardedADMM:
         pad[: local.numel()].copy_(local)
         if local.numel() < self.nmax:
             pad[local.numel():].zero_()
+        self.n_coll += 1
         dist.all_gather_into_tensor(self._gather, pad, group=self.group)
         return self._gather[: self.e.n_total]
 
     # ------------------------------------------------------- distributed z-step (rank weights)
     def _gather_small(self, t):
         out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        self.n_coll += 1
+        if self._stage and t.is_cuda:          # gloo moves host memory: stage (tests on one GPU only)
+            h = torch.empty(out.numel(), dtype=t.dtype)
+            dist.all_gather_into_tensor(h, t.contiguous().cpu(), group=self.group)
+            out.copy_(h)
+        else:
+            dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         return out
 
-    def _gather_counts(self, counts):
-        """every rank's count list -> (world, world) matrix on the host: row r = what r sends"""
-        t = torch.tensor(counts, dtype=torch.int64)
-        if not self._stage:
-            t = t.to(self.e.device)
-        return self._gather_small(t).cpu().numpy().reshape(self.world, self.world)
+    def _to_host(self, t):
+        """the one place the driver waits for the device"""
+        self.n_sync += 1
+        return t.cpu().numpy()
+
+    def _gather_counts(self, counts_dev):
+        """every rank's per-destination counts (an int64 tensor that never left the device) -> the
+        (world, world) matrix on the host, row r = what r sends: one collective, ONE host wait"""
+        return self._to_host(self._gather_small(counts_dev)).reshape(self.world, self.world)
 
     def _alltoall(self, send, send_counts, recv, recv_counts):
         sc, rc = [int(c) for c in send_counts], [int(c) for c in recv_counts]
+        self.n_coll += 1
         if self._stage and send.is_cuda:       # gloo moves host memory: stage (tests on one GPU only)
             r = torch.empty(recv.numel(), dtype=recv.dtype)
             dist.all_to_all_single(r, send.cpu(), rc, sc, group=self.group)
@@ -266,16 +289,34 @@ class ShardedADMM:
         idx = [min(s.numel() - 1, (j + 1) * s.numel() // world) for j in range(world - 1)]
         return s[idx].contiguous()
 
+    @staticmethod
+    def _level_has_violation(bounds, world, level):
+        """does any seam of this tree level have to pool?  Same test as the device's seam set-up
+        (pav.hip: k_zd_seam_setup; oracle/zdist.py: seam_of) on the gathered (first, last, count) triples:
+        the last non-empty chunk on the left ends ABOVE the first non-empty chunk on the right begins."""
+        half = 1 << (level - 1)
+        for k in range((world + 2 * half - 1) // (2 * half)):
+            a0 = 2 * k * half
+            b0 = a0 + half
+            if b0 >= world:
+                continue
+            b1 = min(b0 + half, world)
+            left = [r for r in range(a0, b0) if bounds[r, 2] > 0]
+            right = [r for r in range(b0, b1) if bounds[r, 2] > 0]
+            if left and right and bounds[left[-1], 1] > bounds[right[0], 0]:
+                return True
+        return False
+
     def _z_distributed(self):
         """z-step for rank weights with the sorted order partitioned over the ranks (the CPU
         restatement of every engine call is oracle/zdist.py)."""
         from math import ceil, log2
         e, P, K = self.e, self.world, self.K
-        # 1. sample sort: splitters from regular samples, rows to the owners of their key range
+        # 1. sample sort: splitters from regular samples, rows to the owners of their key range.  The counts
+        # never leave the device until the whole matrix is read with one host wait
         samples_all = self._gather_small(e.zd_sort_local(self.NS))
-        send_counts = e.zd_partition(self._splitters(samples_all, P))
-        cm = self._gather_counts(send_counts)
-        recv_counts = cm[:, self.rank]
+        cm = self._gather_counts(e.zd_partition(self._splitters(samples_all, P)))
+        send_counts, recv_counts = cm[self.rank, :], cm[:, self.rank]
         totals = cm.sum(axis=0)
         nrecv, off = int(totals[self.rank]), int(totals[: self.rank].sum())
         sk, si = e.zd_send_buffers()
@@ -284,9 +325,12 @@ class ShardedADMM:
         self._alltoall(si, send_counts, ri, recv_counts)
         # 2. exact PAV of the own chunk (EHRM: the branch test sums two scalars over the ranks)
         fv = e.zd_prepare(nrecv, off)
-        self._allreduce(fv)
+        if e.needs_branch_sum:
+            self._allreduce(fv)
         e.zd_pav(fv)
-        # 3. merge tree over ranks
+        # 3. merge tree over ranks.  The (first, last, count) triples of all chunks are gathered and looked at
+        # on the host: a level none of whose seams is out of order costs nothing, and the triples stay valid
+        # until a level really pools
         nseams = (P + 1) // 2
         rounds = 1
         s = int(totals.max())
@@ -294,8 +338,13 @@ class ShardedADMM:
             s //= (K + 1)
             rounds += 1
         rounds += 1
+        bounds_all = bounds_host = None
         for level in range(1, int(ceil(log2(P))) + 1):
-            bounds_all = self._gather_small(e.zd_bounds())
+            if bounds_all is None:
+                bounds_all = self._gather_small(e.zd_bounds())
+                bounds_host = self._to_host(bounds_all).reshape(P, 3)
+            if not self._level_has_violation(bounds_host, P, level):
+                continue
             e.zd_seam_setup(self.rank, P, level, bounds_all)
             cand_all = part = None
             for _ in range(rounds):
@@ -305,14 +354,15 @@ class ShardedADMM:
             sums = e.zd_seam_sums(K, cand_all, part, nseams)
             self._allreduce(sums)
             e.zd_seam_fill(sums, nseams)
-        # 4. block values back to the owners of the rows
-        back_counts = e.zd_return_partition(self.nmax, P)
-        bm = self._gather_counts(back_counts)
-        n_back = int(bm[:, self.rank].sum())
+            bounds_all = None            # pooled values changed the chunk ends
+        # 4. block values back to the owners of the rows: the count matrix of the return trip is the
+        # transpose of the forward one (chunk b holds cm[a][b] rows of owner a) - no host wait
+        e.zd_return_partition(self.nmax, P)
+        n_back = int(cm[self.rank, :].sum())
         bi, bu = e.zd_back_send()
         zi, zu = e.zd_back_recv(n_back)
-        self._alltoall(bi, back_counts, zi, bm[:, self.rank])
-        self._alltoall(bu, back_counts, zu, bm[:, self.rank])
+        self._alltoall(bi, recv_counts, zi, send_counts)
+        self._alltoall(bu, recv_counts, zu, send_counts)
         e.zd_scatter(n_back)
 
     def _risk_distributed(self):
@@ -320,16 +370,15 @@ class ShardedADMM:
         ranks: the sample sort of the z-step on the loss keys, a dot product per chunk, one sum."""
         e, P = self.e, self.world
         samples_all = self._gather_small(e.zd_sort_losses(self.NS))
-        send_counts = e.zd_partition(self._splitters(samples_all, P))
-        cm = self._gather_counts(send_counts)
+        cm = self._gather_counts(e.zd_partition(self._splitters(samples_all, P)))
         totals = cm.sum(axis=0)
         nrecv, off = int(totals[self.rank]), int(totals[: self.rank].sum())
         sk, _ = e.zd_send_buffers()
         rk, _ = e.zd_recv_buffers(nrecv)
-        self._alltoall(sk, send_counts, rk, cm[:, self.rank])
+        self._alltoall(sk, cm[self.rank, :], rk, cm[:, self.rank])
         part = e.zd_risk(nrecv, off)
         self._allreduce(part)
-        return float(part.cpu()[0])
+        return float(self._to_host(part)[0])
 
     # ------------------------------------------------------------------- one-time setup
     def setup_synthetic(self, seed=17, class_sep=1.0, flip_y=0.01):
@@ -345,6 +394,7 @@ class ShardedADMM:
     # ------------------------------------------------------------------------ iteration
     def step(self, want_objective=False):
         e = self.e
+        self.n_coll = self.n_sync = 0
         e.phase_m()
         if e.sorted_path and self.world > 1 and self.dist_z:
             self._z_distributed()
@@ -382,4 +432,7 @@ class ShardedADMM:
                 st.objective += self._risk_distributed()
             else:
                 st.objective += e.risk_from_v(self._allgather_rows(e.buf("v")))
+        # how the iteration talked: collectives issued, host waits of this driver (the library's own are
+        # st.host_syncs: the statistics block, the w-step's status word)
+        st.collectives, st.driver_syncs = self.n_coll, self.n_sync
         return st

@@ -295,11 +295,14 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     last = None
-    n_fused = n_mispred = 0
+    n_fused = n_mispred = n_coll = n_drv_sync = n_lib_sync = 0
     for _ in range(a.steps):
         last = step()
         n_fused += int(last.fused)
         n_mispred += int(last.mispredicted)
+        n_coll += int(getattr(last, "collectives", 0))          # set by the multi-GPU driver (dist.py)
+        n_drv_sync += int(getattr(last, "driver_syncs", 0))
+        n_lib_sync += int(last.host_syncs)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -346,7 +349,13 @@ def main():
                        "inner_iters_last": int(last.inner_iters), "phase_ms_last": ({
                            "z": round(last.ms_z, 3), "q": round(last.ms_q, 3), "w": round(last.ms_w, 3),
                            "v": round(last.ms_v, 3), "total": round(last.ms_total, 3)} if a.phase_times else None),
-                       "single_sweep_iterations": n_fused, "rho_mispredictions": n_mispred},
+                       "single_sweep_iterations": n_fused, "rho_mispredictions": n_mispred,
+                       # how an iteration talks (rank 0): collectives issued by the multi-GPU driver, its host
+                       # waits (device -> host reads of count / bound vectors) and the library's own (the
+                       # pinned statistics block, the w-step's status word)
+                       "collectives_per_iteration": round(n_coll / a.steps, 2),
+                       "driver_syncs_per_iteration": round(n_drv_sync / a.steps, 2),
+                       "host_syncs_per_iteration": round(n_lib_sync / a.steps, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_" + dom,

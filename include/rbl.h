@@ -189,14 +189,17 @@ enum { RBL_BUF_M = 0, RBL_BUF_Q = 1, RBL_BUF_RED = 2, RBL_BUF_G = 3, RBL_BUF_V =
        RBL_BUF_ZD_BIDS = 21,   /* int32 x n_total row ids of the chunk, grouped by owner (send back) */
        RBL_BUF_ZD_BU = 22,     /* double x n_total their block values (send back)                  */
        RBL_BUF_ZD_ZIDS = 23,   /* int32 x n       row ids received back                            */
-       RBL_BUF_ZD_ZU = 24      /* double x n      block values received back                       */ };
+       RBL_BUF_ZD_ZU = 24,     /* double x n      block values received back                       */
+       RBL_BUF_ZD_COUNTS = 25  /* int64 x 64      rows of the local sorted run that go to each rank (rbl_zd_partition) */ };
 int  rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles);
 /* ---- distributed z-step for rank-weighted problems on several GPUs ---------------------------
  * (no reference counterpart: the reference is single-process; what is distributed is
  * algorithms.py:88-106.  Driver: admm-for-rank-based-loss_amd/dist.py:_z_distributed; CPU
  * restatement of every call: oracle/zdist.py.)  After rbl_phase_m:
  *   rbl_zd_sort_local        sort the local m (payload: global row id); ZD_SMALL[0,nsamples) = regular samples (NaN = none)
- *   rbl_zd_partition         splitters (nparts-1 doubles, device) -> how many sorted rows go to each rank (host)
+ *   rbl_zd_partition         splitters (nparts-1 doubles, device) -> how many sorted rows go to each rank: left in
+ *                            RBL_BUF_ZD_COUNTS on the device (all-gathered there: ONE host wait for the whole count
+ *                            matrix); send_counts != NULL additionally downloads them (a host wait of its own)
  *   [all-to-all of ZD_SKEYS / ZD_SIDS into ZD_RKEYS / ZD_RIDS]
  *   rbl_zd_prepare           sort the received chunk (n_recv rows, first sorted position sigma_off), prefix sums;
  *                            ZD_SMALL[260,262) = this chunk's EHRM branch sums (to be summed over ranks)
@@ -208,7 +211,10 @@ int  rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles);
  *                rbl_zd_seam_eval    -> ZD_SMALL[512,512+3*world*K)                 [all-reduce] }
  *     rbl_zd_seam_sums       ZD_SMALL[12800,12800+3*nseams)                        [all-reduce]
  *     rbl_zd_seam_fill       pooled block value onto this rank's pooled positions
- *   rbl_zd_return_partition  (row id, value) grouped by owner into ZD_BIDS / ZD_BU; counts per owner (host)
+ *   rbl_zd_return_partition  (row id, value) grouped by owner into ZD_BIDS / ZD_BU.  counts == NULL: no host wait - the
+ *                            count matrix of the return trip is the transpose of the forward one, which the driver
+ *                            holds; counts != NULL downloads them (and the seam-search error flag, otherwise
+ *                            reported by rbl_phase_finish)
  *   [all-to-all into ZD_ZIDS / ZD_ZU]
  *   rbl_zd_scatter           z of the local rows; then rbl_phase_q as usual.
  * Logged objective of rank weights (sum_i sigma_i loss_(i), objective.py:73-82) by the same sample sort:

@@ -18,6 +18,7 @@ class NumpyEngine:
         self.n_total, self.off = n_total, row_offset
         self.wf, self.loss, self.reg, self.l1, self.B, self.tol = weight_function, loss, reg, l1, B, tol
         self.sorted_path = weight_function != "erm"
+        self.needs_branch_sum = weight_function == "ehrm"
         self.sa, self.sb = weights.get_weights(weight_function, n_total, args)
         self.w = 0.001 * reg / self.d / n_total * np.ones(self.d)
         self.z = 0.1 * reg / n_total * np.ones(self.n_local)
@@ -125,7 +126,7 @@ class NumpyEngine:
     def zd_partition(self, splitters):
         sp = splitters.numpy()
         dest = np.searchsorted(sp, self._zd_m, side="right")
-        return [int(np.count_nonzero(dest == j)) for j in range(sp.shape[0] + 1)]
+        return torch.tensor([int(np.count_nonzero(dest == j)) for j in range(sp.shape[0] + 1)], dtype=torch.int64)
 
     def zd_send_buffers(self):
         return torch.from_numpy(self._zd_m.view(np.int64).copy()), torch.from_numpy(self._zd_ids.copy())
@@ -187,7 +188,6 @@ class NumpyEngine:
         order = np.argsort(owner, kind="stable")
         self._zd_bid = self._zd_cid[order].copy()
         self._zd_bu = self._zd_chunk.u[order].copy()
-        return [int(np.count_nonzero(owner == j)) for j in range(world)]
 
     def zd_back_send(self):
         return torch.from_numpy(self._zd_bid), torch.from_numpy(self._zd_bu)

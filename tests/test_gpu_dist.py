@@ -232,8 +232,11 @@ def _make_thread_driver(ShardedADMM, hub):
             hub.bar.wait()
             return out
 
-        def _gather_counts(self, counts):
-            return np.array(self._exchange(list(counts)), dtype=np.int64).reshape(self.world, self.world)
+        def _gather_counts(self, counts_dev):
+            torch.cuda.synchronize()
+            m = np.array([x.cpu().numpy() for x in self._exchange(counts_dev.clone())], dtype=np.int64)
+            hub.bar.wait()
+            return m.reshape(self.world, self.world)
 
         def _alltoall(self, send, send_counts, recv, recv_counts):
             items = self._exchange((send, [int(c) for c in send_counts]))
