@@ -99,6 +99,7 @@ struct rbl_solver {
     bool phase_timing = false;   // rbl_profile_kernels level 2: HIP events around the phases (ms_* of rbl_stats)
     int64_t n_fused = 0, n_mispred = 0;
     bool fused_v_ran = false;
+    int eig_sweeps = 0;    // Jacobi sweeps of the one-time eigendecomposition of G (l2 w-step), 0 = CG is used
     bool keys_ready = false;   // rbl_phase_m left the sort's input (keys of m, global row ids) in sw.keys[0] / vals[0]
     int sort_passes = 0;   // radix passes executed by the z-step in flight
 };
@@ -181,12 +182,20 @@ int alloc_sort(SortWorkspace& sw, int64_t n, bool with_vals) {
     RBL_TRY(dev_alloc((unsigned char**)&sw.spine, sort_spine_bytes()));
     RBL_TRY(dev_alloc(&sw.bin_total, 256));
     RBL_TRY(dev_alloc(&sw.bin_base, 256));
+    RBL_TRY(dev_alloc((unsigned char**)&sw.ghist, sort_ghist_bytes()));
+    RBL_HIP(hipMemset(sw.ghist, 0, sort_ghist_bytes()));
+    if (sort_status_bytes(n) > 0) {
+        RBL_TRY(dev_alloc((unsigned char**)&sw.status, sort_status_bytes(n)));
+        RBL_HIP(hipMemset(sw.status, 0, sort_status_bytes(n)));   // epoch 0 never matches a sort in flight
+        sw.status_tiles = sort_tiles(n);
+    }
+    sw.epoch = 0;
     return RBL_OK;
 }
 
 void free_sort(SortWorkspace& sw) {
     dev_free(sw.keys[0]); dev_free(sw.keys[1]); dev_free(sw.vals[0]); dev_free(sw.vals[1]);
-    dev_free(sw.spine); dev_free(sw.bin_total); dev_free(sw.bin_base);
+    dev_free(sw.spine); dev_free(sw.bin_total); dev_free(sw.bin_base); dev_free(sw.status); dev_free(sw.ghist);
     sw = SortWorkspace{};
 }
 
@@ -199,6 +208,7 @@ int alloc_pav(PavWorkspace& pw, int64_t n) {
     RBL_TRY(dev_alloc(&pw.cph_m, (size_t)nc));
     RBL_TRY(dev_alloc(&pw.cpl_m, (size_t)nc));
     RBL_TRY(dev_alloc(&pw.recs, (size_t)pav_num_recs(n)));
+    RBL_HIP(hipMemset(pw.recs, 0xff, sizeof(SeamRec) * (size_t)pav_num_recs(n)));   // s = -1: no hint from a previous iteration
     RBL_TRY(dev_alloc(&pw.counters, 4));
     RBL_TRY(dev_alloc(&pw.partials, (size_t)reduce_blocks() * 4));
     RBL_TRY(dev_alloc(&pw.branch, 1));
@@ -248,6 +258,7 @@ int alloc_wstep(WstepWorkspace& ww, int64_t ld) {
 }
 
 void free_wstep(WstepWorkspace& ww) {
+    dev_free(ww.eig_Vt); dev_free(ww.eig_V); dev_free(ww.eig_lambda);
     dev_free(ww.yk); dev_free(ww.Gy); dev_free(ww.wn); dev_free(ww.r); dev_free(ww.p); dev_free(ww.scal);
     dev_free(ww.flags);
     free_wstep_pin(ww);
@@ -773,6 +784,7 @@ int rbl_gram_local(rbl_solver* h) {
     RBL_TRY(launch_gram(h->storage, h->D, h->n, h->ld, h->d, h->slab, h->G, h->num_cu, h->stream));
     RBL_HIP(hipStreamSynchronize(h->stream));
     h->gram_local_done = true;
+    h->ww.eig_ok = false;
     return RBL_OK;
 }
 
@@ -786,6 +798,35 @@ int rbl_gram_finish(rbl_solver* h) {
     RBL_TRY(launch_power_iteration(h->G, h->ld, h->ww.yk, h->ww.Gy, h->ww.scal, 100, &lam, h->stream));
     h->L = 1.02 * lam;
     if (!(h->L > 0.0)) h->L = 1.0;
+    // l2 w-step: RBL_RIDGE_EIG=1 replaces the warm-started CG by a one-time eigendecomposition of G (eig.hip).
+    // Opt-in: it makes an iteration 0.13 ms shorter at d = 1000 (14 CG iterations -> 5 small launches) but the
+    // Jacobi sweeps cost 0.8 s of setup there - 6000 iterations to break even, and a solve runs a few hundred
+    h->ww.eig_ok = false;
+    static const bool ridge_eig = [] {
+        const char* e = getenv("RBL_RIDGE_EIG");
+        return e && e[0] == '1';
+    }();
+    if (h->cfg.wstep == RBL_WSTEP_L2 && h->ld <= 2048 && ridge_eig) {
+        const size_t nn = (size_t)h->ld * (size_t)h->ld;
+        if (!h->ww.eig_Vt) {
+            RBL_TRY(dev_alloc(&h->ww.eig_Vt, nn));
+            RBL_TRY(dev_alloc(&h->ww.eig_V, nn));
+            RBL_TRY(dev_alloc(&h->ww.eig_lambda, (size_t)h->ld));
+        }
+        double* Bt = nullptr;
+        unsigned long long* off = nullptr;
+        RBL_TRY(dev_alloc(&Bt, nn));
+        int rc = dev_alloc(&off, 1);
+        int sweeps = 0;
+        if (rc == RBL_OK)
+            rc = launch_eig_jacobi(h->G, h->ld, h->d, Bt, h->ww.eig_Vt, h->ww.eig_V, h->ww.eig_lambda, off, h->stream, &sweeps);
+        (void)hipStreamSynchronize(h->stream);
+        dev_free(Bt);
+        dev_free(off);
+        RBL_TRY(rc);
+        h->ww.eig_ok = sweeps > 0;
+        h->eig_sweeps = sweeps;
+    }
     h->gram_ready = true;
     return RBL_OK;
 }
@@ -1813,8 +1854,16 @@ int rbl_k_sort(int64_t n, const double* keys, double* sorted_keys, uint32_t* per
     sw.spine = (u32*)sc.alloc<unsigned char>(sort_spine_bytes());
     sw.bin_total = sc.alloc<u32>(256);
     sw.bin_base = sc.alloc<u32>(256);
+    sw.ghist = (u32*)sc.alloc<unsigned char>(sort_ghist_bytes());
     double* ms = sc.alloc<double>((size_t)n);
-    SC_CHECK(sw.keys[0] && sw.keys[1] && sw.vals[0] && sw.vals[1] && sw.spine && sw.bin_total && sw.bin_base && ms);
+    SC_CHECK(sw.keys[0] && sw.keys[1] && sw.vals[0] && sw.vals[1] && sw.spine && sw.bin_total && sw.bin_base && sw.ghist && ms);
+    RBL_HIP(hipMemset(sw.ghist, 0, sort_ghist_bytes()));
+    if (sort_status_bytes(n) > 0) {
+        sw.status = (u64*)sc.alloc<unsigned char>(sort_status_bytes(n));
+        SC_CHECK(sw.status);
+        RBL_HIP(hipMemset(sw.status, 0, sort_status_bytes(n)));
+        sw.status_tiles = sort_tiles(n);
+    }
     RBL_TRY(launch_keys_from_m(n, dk, sw.keys[0], sw.vals[0], sc.s));
     RBL_TRY(launch_radix_sort(sw, n, true, sc.s));
     RBL_TRY(launch_unflip_keys(n, sw.keys[0], ms, sc.s));
@@ -1852,6 +1901,7 @@ static int k_pav_common(int loss, int64_t n, const double* sigma_a, const double
     double* partials = sc.alloc<double>((size_t)reduce_blocks() * 4);
     int* branch = sc.alloc<int>(1);
     SC_CHECK(recs && counters && partials && branch);
+    RBL_HIP(hipMemset(recs, 0xff, sizeof(SeamRec) * (size_t)pav_num_recs(n)));   // no hints
     RBL_TRY(launch_prefix(sa, n, lx[0], ch[0], cph[0], cpl[0], sc.s));
     RBL_TRY(launch_prefix(sb, n, lx[1], ch[1], cph[1], cpl[1], sc.s));
     RBL_TRY(launch_prefix(ms, n, lx[2], ch[2], cph[2], cpl[2], sc.s));

@@ -259,9 +259,13 @@ __device__ inline long long lower_bound_ge(const WaveLdsAcc& ac, long long lo, l
 
 // Joins the solved segments [L0, seam) and [seam, R1) (seam violates: u[seam-1] > u[seam]).
 // Returns the pooled range [s*, e*] and its value.
+// hint_s / hint_e (optional, -1 = none): the extents this seam pooled in the previous ADMM iteration.  The block
+// structure moves little from one iteration to the next, so the searches start there (a few probes around the
+// old boundary) instead of galloping away from the seam; any value is safe - a hint only picks the first probe.
 template <int LOSS, typename Acc>
 __device__ inline void seam_merge(const Acc& ac, long long L0, long long seam, long long R1, double rho,
-                                  long long& s_star, long long& e_star, double& x) {
+                                  long long& s_star, long long& e_star, double& x, long long hint_s = -1,
+                                  long long hint_e = -1, double hint_x = __builtin_nan("")) {
     // Both boundary functions are monotone in t:  s(t) = first left position with u > t,
     // e(t) = last right position with u < t.  Every evaluation of Psi therefore narrows the
     // ranges in which later evaluations have to search ([s_lb,s_ub], [e_lb,e_ub]).
@@ -281,6 +285,61 @@ __device__ inline void seam_merge(const Acc& ac, long long L0, long long seam, l
         }
         return sg;
     };
+    // Fast path with a hint for the pooled VALUE (last iteration's): x* is the fixed point of
+    // t -> T(t) = block value of A(t), and sign(T(t) - t) = -sign Psi(t).  From a t close to x* the set A(t) is
+    // (almost) the final one, T(t) lands on x* to rounding, and the iteration stops as soon as A(T(t)) == A(t):
+    // typically 2-3 evaluations (two searches + prefix look-ups each) where the positional search below needs
+    // 10-20.  Bracketed in value space (Psi is increasing); anything unexpected falls through to that search.
+    if (hint_x == hint_x) {
+        double t_lo = ac.val(seam), t_hi = ac.val(seam - 1);      // Psi(t_lo) < 0 < Psi(t_hi): the seam violates
+        double t = hint_x;
+        if (!(t > t_lo && t < t_hi)) t = 0.5 * (t_lo + t_hi);
+        if (t > t_lo && t < t_hi) {
+            auto sets_at = [&](double tt, long long& ss, long long& ee, double& xx) -> double {
+                ss = upper_bound_gt(ac, s_lb < s_ub ? s_lb : s_ub, s_ub, tt);
+                const long long eb = e_ub + 1;
+                ee = lower_bound_ge(ac, e_lb + 1 < eb ? e_lb + 1 : eb, eb, tt) - 1;
+                const double A = ac.sum_a(ss, ee + 1), M = ac.sum_m(ss, ee + 1), cnt = (double)(ee + 1 - ss);
+                xx = block_value<LOSS>(A, M, cnt, rho);
+                const double sg = (LOSS == 0) ? A * rbl::sigmoid1(tt) + rho * (cnt * tt - M) : tt - xx;
+                if (sg > 0.0) {
+                    s_ub = ss;
+                    e_ub = ee;
+                } else if (sg < 0.0) {
+                    s_lb = ss;
+                    e_lb = ee;
+                }
+                return sg;
+            };
+            long long s1, e1, s2, e2;
+            double x1, x2;
+            double sg = sets_at(t, s1, e1, x1);
+            for (int it = 0; it < 10; ++it) {
+                if (sg > 0.0) t_hi = t; else if (sg < 0.0) t_lo = t;
+                double tn = x1;
+                const bool newton = tn > t_lo && tn < t_hi;
+                if (!newton) tn = 0.5 * (t_lo + t_hi);
+                if (!(tn > t_lo && tn < t_hi)) break;          // the bracket cannot be split any further
+                const double sg2 = sets_at(tn, s2, e2, x2);
+                if (newton && s2 == s1 && e2 == e1) {          // A(T(t)) == A(t): consistent, x1 is the root
+                    s_star = s1;
+                    e_star = e1;
+                    x = x1;
+                    return;
+                }
+                t = tn;
+                s1 = s2;
+                e1 = e2;
+                x1 = x2;
+                sg = sg2;
+            }
+            // not settled (rare): the positional search below runs exactly as without a value hint
+            s_lb = L0;
+            s_ub = seam;
+            e_lb = seam - 1;
+            e_ub = R1 - 1;
+        }
+    }
     // s* = first left position whose value exceeds x*  <=>  first i with Psi(u[i]) > 0.
     // Psi(u[seam-1]) > 0 is known (the seam violates); gallop leftwards from the seam (x8 per
     // step), then close the bracket by interpolating on the VALUES of Psi (monotone and smooth
@@ -289,8 +348,38 @@ __device__ inline void seam_merge(const Acc& ac, long long L0, long long seam, l
     long long hi = seam - 1, lo = L0 - 1;  // pred(hi) true, pred(lo) false (L0-1: virtual)
     double f_hi = 1.0, f_lo = 0.0;
     bool have_lo = false, have_hi = false;
+    long long from = seam - 1;             // the gallop leaves from here (leftwards)
+    bool gallop_left = true;
+    if (hint_s >= L0 && hint_s < seam - 1) {
+        const double f = psi_at(ac.val(hint_s), hint_s + 1, R1 - 1);
+        if (f > 0.0) {                     // still pooled: s* <= hint, continue leftwards from it
+            hi = hint_s;
+            f_hi = f;
+            have_hi = true;
+            from = hint_s;
+        } else {                           // s* moved towards the seam: gallop rightwards from the hint
+            lo = hint_s;
+            f_lo = f;
+            have_lo = true;
+            gallop_left = false;
+            for (long long off = 1;; off <<= 3) {
+                const long long p = hint_s + off;
+                if (p >= hi) break;
+                const double g = psi_at(ac.val(p), p + 1, R1 - 1);
+                if (g > 0.0) {
+                    hi = p;
+                    f_hi = g;
+                    have_hi = true;
+                    break;
+                }
+                lo = p;
+                f_lo = g;
+            }
+        }
+    }
+    if (gallop_left)
     for (long long off = 1; hi > L0; off <<= 3) {
-        long long p = seam - 1 - off;
+        long long p = from - off;
         if (p < L0) p = L0;
         const double f = psi_at(ac.val(p), p + 1, R1 - 1);
         if (f > 0.0) {
@@ -337,8 +426,38 @@ __device__ inline void seam_merge(const Acc& ac, long long L0, long long seam, l
     lo = seam;
     hi = R1;  // pred(lo) true, pred(hi) false (R1: virtual)
     have_lo = have_hi = false;
+    from = seam;
+    bool gallop_right = true;
+    if (hint_e > seam && hint_e <= R1 - 1) {
+        const double f = psi_at(ac.val(hint_e), L0, hint_e - 1);
+        if (f < 0.0) {                     // still pooled: e* >= hint, continue rightwards from it
+            lo = hint_e;
+            f_lo = f;
+            have_lo = true;
+            from = hint_e;
+        } else {                           // e* moved towards the seam: gallop leftwards from the hint
+            hi = hint_e;
+            f_hi = f;
+            have_hi = true;
+            gallop_right = false;
+            for (long long off = 1;; off <<= 3) {
+                const long long p = hint_e - off;
+                if (p <= lo) break;
+                const double g = psi_at(ac.val(p), L0, p - 1);
+                if (g < 0.0) {
+                    lo = p;
+                    f_lo = g;
+                    have_lo = true;
+                    break;
+                }
+                hi = p;
+                f_hi = g;
+            }
+        }
+    }
+    if (gallop_right)
     for (long long off = 1; lo < R1 - 1; off <<= 3) {
-        long long p = seam + off;
+        long long p = from + off;
         if (p > R1 - 1) p = R1 - 1;
         const double f = psi_at(ac.val(p), L0, p - 1);
         if (f < 0.0) {
@@ -554,7 +673,8 @@ template <int LOSS>
 __global__ __launch_bounds__(PV_THREADS) void k_pav_seam_wave(double* __restrict__ u, long long n, long long half,
                                                                Prefix pa_, Prefix pb_, Prefix pm, const int* branch,
                                                                double rho, SeamRec* __restrict__ recs,
-                                                               long long nseams, u32* __restrict__ merge_counter) {
+                                                               long long nseams, u32* __restrict__ merge_counter,
+                                                               SeamRec* __restrict__ hints) {
     const long long k = ((long long)blockIdx.x * PV_THREADS + threadIdx.x) >> 6;   // wave-uniform
     const int lane = threadIdx.x & 63;
     if (k >= nseams) return;
@@ -568,12 +688,24 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_seam_wave(double* __restrict
     if (R1 > n) R1 = n;
     long long s_star, e_star;
     double x;
-    seam_merge<LOSS>(ac, seam - half, seam, R1, rho, s_star, e_star, x);
+    long long hs = -1, he = -1;
+    double hx = __builtin_nan("");
+    if (hints) {   // what this seam pooled in the previous iteration (wave-uniform loads)
+        hs = hints[k].s;
+        he = hints[k].e;
+        if (hs >= 0) hx = hints[k].x;
+    }
+    seam_merge<LOSS>(ac, seam - half, seam, R1, rho, s_star, e_star, x, hs, he, hx);
     if (lane == 0) {
         atomicAdd(merge_counter, 1u);
         recs[k].s = s_star;
         recs[k].e = e_star;
         recs[k].x = x;
+        if (hints) {
+            hints[k].s = s_star;
+            hints[k].e = e_star;
+            hints[k].x = x;
+        }
     }
 }
 
@@ -940,7 +1072,9 @@ __global__ void k_zd_scatter(long long n, const u32* __restrict__ ids, const dou
 }  // namespace
 
 int64_t pav_num_chunks(int64_t n) { return n / PAV_CHUNK + 1; }
-int64_t pav_num_recs(int64_t n) { return n / (2 * PB_TILE) + 2; }
+// per-level scratch records [0, L) followed by the hints of every upper level (sum over levels <= 2 L + 64)
+static int64_t pav_level_recs(int64_t n) { return n / (2 * PB_TILE) + 2; }
+int64_t pav_num_recs(int64_t n) { return 3 * pav_level_recs(n) + 64; }
 
 int launch_prefix(const double* x, int64_t n, double* locx, double* chunk_tot, double* cph, double* cpl,
                   hipStream_t s) {
@@ -1039,9 +1173,16 @@ int launch_pav_tree(int loss, int64_t n, double rho, const double* ms, const dou
         hipLaunchKernelGGL(k_pav_bottom<1>, dim3(tiles), dim3(PV_THREADS), 0, s, ms, sa, sb, branch, rho, (long long)n, u,
                            merge_counter, u0a, u0b, thread_seams ? 0 : 1);
     // upper levels: one WAVE per seam (64-ary inner searches), pooled ranges written by a fill pass
+    static const bool no_hints = [] {
+        const char* e = getenv("RBL_PAV_NO_HINTS");       // cold searches every iteration, for comparison
+        return e && e[0] == '1';
+    }();
+    SeamRec* hint_base = no_hints ? nullptr : recs + pav_level_recs(n);
     int level = PB_TILE_LOG + 1;
     for (long long half = PB_TILE; half < n; half <<= 1, ++level) {
         const long long nseams = (n + 2 * half - 1) / (2 * half);
+        SeamRec* hints = hint_base;
+        if (hint_base) hint_base += nseams;
         if (thread_seams) {
             const unsigned grid = pv_grid(nseams, PV_THREADS, 1LL << 30);
             if (loss == RBL_LOSS_BCE)
@@ -1054,10 +1195,10 @@ int launch_pav_tree(int loss, int64_t n, double rho, const double* ms, const dou
             const unsigned grid = pv_grid(nseams * 64, PV_THREADS, 1LL << 30);
             if (loss == RBL_LOSS_BCE)
                 hipLaunchKernelGGL(k_pav_seam_wave<0>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, half, pa, pb,
-                                   pm, branch, rho, recs, nseams, merge_counter);
+                                   pm, branch, rho, recs, nseams, merge_counter, hints);
             else
                 hipLaunchKernelGGL(k_pav_seam_wave<1>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, half, pa, pb,
-                                   pm, branch, rho, recs, nseams, merge_counter);
+                                   pm, branch, rho, recs, nseams, merge_counter, hints);
         }
         hipLaunchKernelGGL(k_pav_fill, dim3((unsigned)((n + PF_CHUNK - 1) / PF_CHUNK)), dim3(256), 0, s, u, (long long)n, level,
                            recs);

@@ -105,8 +105,16 @@ struct SortWorkspace {
     u32* spine;      // 256 * RS_MAX_BLOCKS
     u32* bin_total;  // 256
     u32* bin_base;   // 256
+    // single-kernel passes (decoupled look-back): tile status words, global digit histograms / bases, tile tickets
+    u64* status;     // sort_status_bytes(n): 8 passes x tiles x 256 words; NULL = three-kernel passes
+    u32* ghist;      // 8 x 256 digit counts (zero between sorts), then 8 x 256 bases, then 8 tickets
+    u32 epoch;       // tag of the status words of the sort in flight (host side)
+    int64_t status_tiles;   // tiles the status array was sized for
 };
 size_t sort_spine_bytes();
+size_t sort_status_bytes(int64_t n);   // 0: n too large for the single-kernel passes
+size_t sort_ghist_bytes();
+int64_t sort_tiles(int64_t n);
 // sorts keys[0]/vals[0] ascending (stable); result ends in keys[0]/vals[0]
 // key_bits: number of low key bits that can differ (digits above are skipped)
 int launch_radix_sort(SortWorkspace& ws, int64_t n, bool with_vals, hipStream_t s, int key_bits = 64);
@@ -186,6 +194,9 @@ struct WstepWorkspace {
     double* scal;   // small device scalars: [0]=t, [1]=rr, ...
     int* flags;     // [0]=done, [1]=iters
     int* pin;       // host-pinned, device-visible: [0..3] = status block of the active-set lasso kernel, [4..5] = CG (done, iterations)
+    // l2 w-step: G = V diag(lambda) V^T computed once by rbl_gram_finish (eig.hip); NULL / false: CG
+    double *eig_Vt, *eig_V, *eig_lambda;
+    bool eig_ok;
     int last_iters; // CG iterations of the previous w-step (sizes the next batch)
     int last_fista; // the same for FISTA; pin[6..7] = its (done, iterations)
 };
@@ -229,6 +240,13 @@ bool sweep_v_supported(int storage, int64_t ld);
 int launch_sweep_v(int storage, const void* D, int64_t n, int64_t ld, const double* w, const double* z, double* lam,
                    double* v, double rho, double* partials, double* red, int num_cu, hipStream_t s, hipEvent_t main_done);
 int launch_symv(const double* G, int64_t ld, const double* x, double* y, hipStream_t s);
+int launch_symv_ab(const double* G, int64_t ld, const double* x, double* y, double alpha, double beta, hipStream_t s);   // y = alpha G x + beta x
+
+// ---- eig.hip: one-time eigendecomposition of G for the l2 w-step
+int launch_eig_jacobi(const double* G, int64_t ld, int64_t d, double* Bt, double* Vt, double* V, double* lambda,
+                      unsigned long long* offmax_dev, hipStream_t s, int* sweeps_out);
+int launch_ridge_eig(const double* G, const double* Vt, const double* V, const double* lambda, int64_t ld, const double* q,
+                     double rho, double reg, double* w, double* tmp1, double* tmp2, hipStream_t s);
 
 // ---- gram.hip ---------------------------------------------------------------------------
 size_t gram_slab_bytes(int64_t d, int num_cu, int64_t n);

@@ -570,6 +570,12 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
         rbl_set_error("w-step: d=%lld exceeds the single-block update limit %d", (long long)ld, UPD_THREADS * UPD_PER);
         return RBL_ERR_INVALID;
     }
+    if (wstep == RBL_WSTEP_L2 && ws.eig_ok) {
+        // (rho G + reg I) w = rho q through the one-time eigendecomposition of G (eig.hip): two mat-vecs for any rho,
+        // plus one step of iterative refinement against G itself
+        if (iters_host) *iters_host = 1;
+        return launch_ridge_eig(G, ws.eig_Vt, ws.eig_V, ws.eig_lambda, ld, q, rho, reg, w, ws.Gy, ws.r, s);
+    }
     if (wstep == RBL_WSTEP_L2) {
         // (rho G + reg I) w = rho q.  The warm-started CG needs about as many iterations as last
         // time: one batch of that many (+2) is enqueued, its last update publishes (done,
@@ -640,6 +646,12 @@ int finish_wstep_l1(const double* G, int64_t ld, const double* q, double rho, do
 
 int launch_symv(const double* G, int64_t ld, const double* x, double* y, hipStream_t s) {
     hipLaunchKernelGGL(k_symv, dim3(symv_grid(ld)), dim3(256), 0, s, G, (long long)ld, x, y, 1.0, 0.0, (const int*)nullptr);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_symv_ab(const double* G, int64_t ld, const double* x, double* y, double alpha, double beta, hipStream_t s) {
+    hipLaunchKernelGGL(k_symv, dim3(symv_grid(ld)), dim3(256), 0, s, G, (long long)ld, x, y, alpha, beta, (const int*)nullptr);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

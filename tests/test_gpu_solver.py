@@ -301,6 +301,36 @@ def test_w_step_ahead_of_the_host_is_invisible(R):
     assert np.array_equal(np.array(r["h"]), h0) and np.array_equal(np.array(r["w"]), st0["w"])
 
 
+def test_ridge_by_eigendecomposition_variant():
+    """RBL_RIDGE_EIG=1: the l2 w-step through a one-time Jacobi eigendecomposition of G (eig.hip) - opt-in
+    (its setup does not pay back within a solve), kept exact: the same iterates as the CG default and as the
+    oracle, in a process of its own (the variable is read once)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+        "import admm_for_rank_based_loss_amd as R\n"
+        "from oracle import problems, admm\n"
+        "for n, d, kw in ((1500, 24, dict(weight_function='superquantile', loss='binary_cross_entropy', l2_reg=0.01, args=[0.5])),\n"
+        "                 (2000, 301, dict(weight_function='erm', loss='hinge', l2_reg=0.01)),\n"
+        "                 (900, 1001, dict(weight_function='aorr', loss='binary_cross_entropy', l2_reg=1e-4, args=[0.2, 0.8]))):\n"
+        "    X, y = problems.make_problem(n, d, seed=5)\n"
+        "    ref = admm.admm_solve(X, y, max_iter=12, mode='exact', tol=0.0, **kw)\n"
+        "    s = R.ADMMmethod(X, y, max_iter=12, tol=0.0, storage='f64', **kw)._s\n"
+        "    tol = 1e-9 if kw['loss'] == 'binary_cross_entropy' else 1e-7\n"
+        "    for i in range(12):\n"
+        "        st = s.step(True)\n"
+        "        assert st.inner_iters == 1, st.inner_iters\n"
+        "        assert abs(st.primal - ref.primal[i]) <= tol * max(1.0, ref.primal[i]), (d, i)\n"
+        "        assert abs(st.dual - ref.dual[i]) <= tol * max(1.0, ref.dual[i]), (d, i)\n"
+        "    assert np.max(np.abs(s.get_state()['w'] - ref.w)) <= tol * max(1.0, np.max(np.abs(ref.w)))\n"
+        "print('OK')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RBL_RIDGE_EIG="1"), capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (out.stdout[-500:], out.stderr[-2000:])
+
+
 def test_stop_tolerance_is_literal(R):
     """algorithms.py:137 stops when both residuals are below tol.  The library takes tol literally:
     with the reference default it reports convergence at the iteration the oracle stops at; with
