@@ -86,6 +86,8 @@ SIGNATURES = {
     "rbl_fair_statistics": (C.c_int, [_P, _P, _P, C.c_double, _P]),
     "rbl_phase_m": (C.c_int, [_P]),
     "rbl_phase_z": (C.c_int, [_P, _P]),
+    "rbl_phase_z_external": (C.c_int, [_P, _P]),
+    "rbl_phase_w_external": (C.c_int, [_P, _P]),
     "rbl_zd_sort_local": (C.c_int, [_P, C.c_int]),
     "rbl_zd_partition": (C.c_int, [_P, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "rbl_zd_prepare": (C.c_int, [_P, C.c_int64, C.c_int64]),

@@ -232,6 +232,20 @@ class Solver:
     def phase_z(self, m_all_ptr=None):
         _lib.check(self.lib.rbl_phase_z(self._h, C.c_void_p(m_all_ptr) if m_all_ptr else None))
 
+    def phase_z_external(self, z):
+        """a z-step computed by the caller (overridden hook): n values for this handle's rows"""
+        z = _lib.f64(z).reshape(-1)
+        if z.size != self.n:
+            raise ValueError(f"z has {z.size} entries, expected {self.n}")
+        _lib.check(self.lib.rbl_phase_z_external(self._h, _lib.ptr(z)))
+
+    def phase_w_external(self, w):
+        """a w-step computed by the caller (overridden hook): d values"""
+        w = _lib.f64(w).reshape(-1)
+        if w.size != self.d:
+            raise ValueError(f"w has {w.size} entries, expected {self.d}")
+        _lib.check(self.lib.rbl_phase_w_external(self._h, _lib.ptr(w)))
+
     def phase_q(self):
         _lib.check(self.lib.rbl_phase_q(self._h))
 

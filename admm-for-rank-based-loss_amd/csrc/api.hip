@@ -974,6 +974,55 @@ int rbl_phase_z(rbl_solver* h, const void* m_all_dev) {
     return RBL_OK;
 }
 
+int rbl_phase_z_external(rbl_solver* h, const double* z) {
+    RBL_ENTER_ITER(h);
+    if (!z) {
+        rbl_set_error("phase_z_external: z is NULL");
+        return RBL_ERR_INVALID;
+    }
+    RBL_TRY(rbl_phase_m(h));   // opens the iteration (step_rho); a no-op for what it has computed already
+    RBL_HIP(hipMemcpyAsync(h->z, z, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+    RBL_HIP(hipStreamSynchronize(h->stream));   // the caller's buffer may go away
+    rbl_note_host_sync();
+    // a z-step the previous single-sweep pass did ahead of time (z_next, q, ||z||^2) is void: the unfused kernels
+    // rebuild q in rbl_phase_q; erm keeps c = z + lambda/rho and ||z||^2 next to z (launch_erm_zc), rebuild both
+    h->z_ready = false;
+    h->keys_ready = false;
+    if (!h->sorted_path) {
+        RBL_TRY(launch_make_c(h->n, h->z, h->lam, h->step_rho, h->c, h->stream));
+        if (h->fused_ok) RBL_TRY(launch_sumsq(h->n, h->z, h->partials, q_zz(h), h->stream));
+    }
+    if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[1], h->stream));
+    return RBL_OK;
+}
+
+int rbl_phase_w_external(rbl_solver* h, const double* w) {
+    RBL_ENTER_ITER(h);
+    if (!w) {
+        rbl_set_error("phase_w_external: w is NULL");
+        return RBL_ERR_INVALID;
+    }
+    // w_prev = w_k: while a w-step enqueued ahead of time is in flight w_k already sits in w_prev
+    if (!h->spec_w)
+        RBL_HIP(hipMemcpyAsync(h->w_prev, h->w, sizeof(double) * h->ld, hipMemcpyDeviceToDevice, h->stream));
+    h->spec_w = false;
+    h->spec_timed = false;
+    RBL_HIP(hipMemsetAsync(h->w, 0, sizeof(double) * h->ld, h->stream));
+    RBL_HIP(hipMemcpyAsync(h->w, w, sizeof(double) * h->d, hipMemcpyHostToDevice, h->stream));
+    RBL_HIP(hipStreamSynchronize(h->stream));
+    rbl_note_host_sync();
+    RBL_TRY(launch_w_stats(h->ld, h->w, h->w_prev, h->red2, h->stream));   // dual residual, regulariser terms
+    // no rho prediction was made for this w: the dual update runs unfused, and the d-space recurrence for
+    // D^T lambda is re-seeded by the next rbl_phase_q
+    h->pred_valid = false;
+    h->p_valid = h->p_pending = false;
+    h->z_ready = false;        // (a caller that skipped rbl_phase_q: nothing of a previous pass is pending any more)
+    h->v_valid = false;
+    h->inner_iters = 0;
+    if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[3], h->stream));
+    return RBL_OK;
+}
+
 int rbl_phase_q(rbl_solver* h) {
     RBL_ENTER_ITER(h);
     if (!(h->fused_ok && h->z_ready)) {

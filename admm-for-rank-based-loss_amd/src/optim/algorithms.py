@@ -132,7 +132,11 @@ class Optimizer:
         self.time_array = [0]
         self.store = True
 
-    # ---- sub-problem hooks (:88-116, :186-207); subclasses may override and return arrays ----
+    # ---- sub-problem hooks (:88-116, :186-207).  A subclass may override ``z_subproblem`` / ``w_subproblem`` (or
+    # the ``_z_subproblem`` / ``_w_subproblem`` wrappers the reference's ADMMmethod defines, :186-207) and return
+    # its own (n,1) / (d,1) array: main_loop then hands it to the library, which rebuilds what the later
+    # phases derive from it (c = z + lambda/rho, ||z||^2; w_prev, the dual residual) - see
+    # include/rbl.h: rbl_phase_z_external / rbl_phase_w_external.  The defaults leave the result on the GPU.
     def z_subproblem(self):
         self._s.phase_m()          # m = D w - lambda/rho                          :89
         self._s.phase_z()          # sort + PAV (prox only for erm) + scatter      :92-104
@@ -153,10 +157,10 @@ class Optimizer:
     def main_loop(self, i, t_start, verbose):
         z = self._z_subproblem()
         if not isinstance(z, _OnDevice):
-            self._s.set_state(z=np.asarray(z, dtype=np.float64).reshape(-1))
+            self._s.phase_z_external(np.asarray(z, dtype=np.float64).reshape(-1))
         w = self._w_subproblem()
         if not isinstance(w, _OnDevice):
-            self._s.set_state(w=np.asarray(w, dtype=np.float64).reshape(-1))
+            self._s.phase_w_external(np.asarray(w, dtype=np.float64).reshape(-1))
         need_obj = self.store or verbose
         self._s.phase_dual(want_objective=need_obj)    # v = D w, lambda += rho (z - v)    :132
         st = self._s.phase_finish()                    # residuals, stop test, rho rule    :135-157

@@ -166,6 +166,13 @@ int  rbl_phase_m(rbl_solver* h);
 /* B: z-step (algorithms.py:92-104).  m_all_dev: device pointer to the n_total gathered
  * m values (rank order) or NULL when n == n_total or weight_function == erm. */
 int  rbl_phase_z(rbl_solver* h, const void* m_all_dev);
+/* B': the caller's own z-step (an overridden Optimizer.z_subproblem that returns an array, algorithms.py:88-106 /
+ * :186-188): z (n host doubles, this process's rows) replaces the library's; everything the later phases derive
+ * from z is rebuilt.  Runs rbl_phase_m first if the iteration has not been opened yet. */
+int  rbl_phase_z_external(rbl_solver* h, const double* z);
+/* D': the caller's own w-step (an overridden w_subproblem, algorithms.py:109-116): w (d host doubles, identical
+ * on every rank) becomes w_{k+1}; the previous iterate is kept for the dual residual.  Call after rbl_phase_q. */
+int  rbl_phase_w_external(rbl_solver* h, const double* w);
 /* C: local q = D^T (z + lambda/rho) -> RBL_BUF_Q (d doubles, to be summed over ranks) */
 int  rbl_phase_q(rbl_solver* h);
 /* D: replicated w-step from the summed q (algorithms.py:109-116,190-207) */

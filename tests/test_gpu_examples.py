@@ -70,6 +70,33 @@ def test_run_aorr_ratio_rows(tmp_path):
         assert len(lines) == 3 and len(lines[0].split(",")) == ref.iters + 1
 
 
+def test_run_aorr_fixed_rows(tmp_path):
+    """run_AoRR_fixed.py:82-156 call sequence (per-class 50/25/25 split, intercept column, aorr_dc with fixed
+    ranks [k, m], test objective with args [1, 0]) against the CPU oracle's exact mode on the same split,
+    both losses; the hand-over to the DCA baseline (:188-190)."""
+    from oracle import admm, weights, objective
+    for loss, k, m in (("hinge", 80, 3), ("binary_cross_entropy", 60, 5)):
+        out = tmp_path / f"rows_{loss}.csv"
+        r = _load("run_aorr_fixed").main(["--rows", "690", "--cols", "14", "--loss", loss, "--k", str(k), "--m", str(m),
+                                          "--max-iter", "80", "--quiet", "--out", str(out)])
+        Xtr, ytr = r["X_train"], r["y_train"]
+        n = Xtr.shape[0]
+        assert Xtr.shape[1] == 15 and np.all(Xtr[:, -1] == 1.0) and 300 <= n <= 345       # half of every class + intercept
+        ref = admm.admm_solve(Xtr, ytr, "aorr_dc", loss, l2_reg=1e-4, args=[k, m], max_iter=80, mode="exact", tol=1e-4)
+        train_losses, times, acc = r["rows"]
+        assert len(train_losses) == len(times) and abs(len(train_losses) - (ref.iters + 1)) <= 1 and times[0] == 0
+        assert abs(train_losses[-1] - ref.objective[len(train_losses) - 1]) <= 1e-6 * max(1e-3, abs(ref.objective[len(train_losses) - 1])), loss
+        # sigma handed to the DCA baseline: the aorr_dc weights of objective.py:139-145 (pinned by golden g8)
+        sa, _ = weights.get_weights("aorr_dc", n, [k, m])
+        assert np.allclose(r["sigma"], sa, rtol=0, atol=1e-15) and r["reg"] == 1e-4
+        assert abs(r["train_cb"] - objective.objective(loss, sa, Xtr, ytr, r["w"], l2_reg=1e-4)) <= 1e-10 * max(1.0, abs(r["train_cb"]))
+        # the test objective was built with args [1, 0] (run_AoRR_fixed.py:153)
+        st, _ = weights.get_weights("aorr_dc", r["X_test"].shape[0], [1, 0])
+        assert abs(r["test_cb"] - objective.objective(loss, st, r["X_test"], r["y_test"], r["w"], l2_reg=1e-4)) <= 1e-10 * max(1.0, abs(r["test_cb"]))
+        assert 0.0 <= acc[0] <= 1.0
+        assert len(out.read_text().strip().splitlines()) == 3
+
+
 def test_run_ehrm_rows():
     """run_EHRM.py:21-41 call sequence (group-carrying split, ehrm / BCE / l2 = 0.01 / B = -5, accuracy and
     the six fairness statistics) on synthetic data with a group attribute."""

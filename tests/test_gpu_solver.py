@@ -254,6 +254,69 @@ def test_api_surface_and_errors(R):
         R.ADMMmethod(X, y, "erm", l2_reg=0.1, B=-5)
 
 
+@pytest.mark.parametrize("kw,d", [
+    (dict(weight_function="erm", loss="binary_cross_entropy", l1_reg=0.01), 160),      # single-sweep path
+    (dict(weight_function="erm", loss="hinge", l2_reg=0.01), 24),                        # two-sweep erm path
+    (dict(weight_function="superquantile", loss="binary_cross_entropy", l2_reg=0.01, args=[0.5]), 40),
+    (dict(weight_function="ehrm", loss="binary_cross_entropy", l2_reg=0.01, B=-5), 140),
+], ids=["erm_l1_fused", "erm_hinge_l2", "superq_l2", "ehrm_l2_vsweep"])
+def test_overridden_subproblem_hooks(R, kw, d):
+    """The reference's sub-problem hooks (algorithms.py:88-116, :186-207) can be overridden: a subclass whose
+    z_subproblem / w_subproblem return their OWN arrays - here the CPU oracle's exact solves on the state read
+    from the solver - must drive the same ADMM run as the built-in device steps (1e-9; hinge 1e-7), with the
+    residuals, the rho schedule and the logged objective computed by the library from the injected z and w.
+    Three subclasses: only z overridden, only w overridden, both."""
+    from oracle import problems, admm, wstep, weights
+    X, y = problems.make_problem(1200, d, seed=91)
+    nit = 12
+    ref = admm.admm_solve(X, y, max_iter=nit, mode="exact", tol=0.0, **kw)
+    n = X.shape[0]
+    wf, loss = kw["weight_function"], kw["loss"]
+    sa, sb = weights.get_weights(wf, n, kw.get("args"))
+    D = -y.reshape(-1, 1) * X
+    G = D.T @ D
+    Lmax = 1.0001 * wstep.lambda_max(G)
+    reg = kw.get("l1_reg") or kw.get("l2_reg")
+
+    def z_by_oracle(self):
+        m = (D @ self.w - self.lagrangian / self.rho).reshape(-1)
+        z, _ = admm.z_step_exact(wf, loss, sa, sb, kw.get("B"), self.rho, m)
+        return z.reshape(-1, 1)
+
+    def w_by_oracle(self):
+        rho = self.rho
+        q = D.T @ (self.z + self.lagrangian / rho).reshape(-1)
+        if "l1_reg" in kw:
+            w, _ = wstep.lasso_gram_exact(G, q, reg / (2 * rho), self.w.reshape(-1), Lmax)
+        else:
+            w = wstep.ridge_gram_exact(G, q, rho, reg)
+        return w.reshape(-1, 1)
+
+    class ZHook(R.ADMMmethod):
+        z_subproblem = z_by_oracle
+
+    class WHook(R.ADMMmethod):
+        _w_subproblem = w_by_oracle          # the wrapper name the reference's ADMMmethod uses (:190)
+
+    class BothHooks(R.ADMMmethod):
+        z_subproblem = z_by_oracle
+        w_subproblem = w_by_oracle
+
+    tol = 1e-9 if loss == "binary_cross_entropy" else 1e-7
+    for cls in (ZHook, WHook, BothHooks):
+        s = cls(X, y, max_iter=nit, tol=0.0, storage="f64", **kw)
+        s.start_store(X, y, **{k: v for k, v in kw.items() if k != "B"})
+        _quiet(s.main_loop, verbose=False)
+        assert len(s.train_losses) == nit + 1
+        assert np.allclose(s.train_losses, ref.objective[: nit + 1], rtol=tol, atol=tol), (cls.__name__, s.train_losses[-1])
+        st = s._last
+        assert abs(st.primal - ref.primal[-1]) <= tol * max(1.0, ref.primal[-1]), cls.__name__
+        assert abs(st.dual - ref.dual[-1]) <= tol * max(1.0, ref.dual[-1]), cls.__name__
+        assert abs(st.rho - ref.rho[-1]) <= 1e-15 * ref.rho[-1]
+        assert np.max(np.abs(s.w.reshape(-1) - ref.w)) <= tol * max(1.0, np.max(np.abs(ref.w))), cls.__name__
+        assert np.max(np.abs(s.lagrangian.reshape(-1) - ref.lam)) <= 10 * tol * max(1e-3, np.max(np.abs(ref.lam)))
+
+
 def test_w_step_ahead_of_the_host_is_invisible(R):
     """Single-sweep lasso iterations enqueue the NEXT w-step before the host has read the
     current statistics (api.hip: rbl_phase_finish).  Whatever is called between two iterations
