@@ -116,7 +116,7 @@ def _initial_state(s, cfg, n_total, d):
     reg, wf = cfg["reg"], cfg["weight_function"]
     rho0 = 1e-4 if wf == "ehrm" else (2e-7 if wf in ("aorr", "aorr_dc") else 1e-5)
     s.set_state(w=np.full(d, 0.001 * reg / d / n_total), z=np.full(s.n, 0.1 * reg / n_total),
-                lam=np.full(s.n, 0.1 * reg / n_total), rho=rho0, iter=0)
+                lam=np.full(s.n, 0.1 * reg / n_total), rho=rho0, iter=0, smooth_t=1.0)   # t: smoothADMMmethod's default
 
 
 def f_star_run(make_solver, cfg, n_total, d, tol=1e-8, max_iter=2000):
