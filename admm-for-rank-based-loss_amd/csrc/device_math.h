@@ -107,6 +107,14 @@ __device__ inline double prox_bce_warm(double sigma, double rho, double m, doubl
     return x;
 }
 
+// Cold start with a first-order estimate: the root of sigma*sigmoid(x) + rho*(x - m) is m - (sigma/rho)*sigmoid(m) up
+// to O((sigma/rho)^2) (sigma/rho is ~1e-3 for single elements at the bench sizes: two Newton steps instead of
+// six to eight from x = m); sm = sigmoid(m) may be shared by callers that solve several sigma for one m.  The
+// safeguards are prox_bce's, so any estimate gives the same root to rounding.
+__device__ inline double prox_bce_est(double sigma, double rho, double m, double sm) {
+    return prox_bce_warm(sigma, rho, m, m - (sigma / rho) * sm);
+}
+
 // sum over the 64 lanes of a wave, returned to every lane: butterfly inside each 16-lane row
 // with DPP (no LDS round trips), then the four row sums through scalar registers.
 __device__ inline double dpp_mov(double x, const int ctrl_sel) {
@@ -144,6 +152,12 @@ __device__ inline double prox_hinge(double sigma, double rho, double m) {
 template <int LOSS>
 __device__ inline double prox(double sigma, double rho, double m) {
     return LOSS == 0 ? prox_bce(sigma, rho, m) : prox_hinge(sigma, rho, m);
+}
+
+// element prox with the first-order estimate as the starting point (level 0 of the PAV tree, the EHRM branch test)
+template <int LOSS>
+__device__ inline double prox_est(double sigma, double rho, double m) {
+    return LOSS == 0 ? prox_bce_est(sigma, rho, m, sigmoid1(m)) : prox_hinge(sigma, rho, m);
 }
 
 template <int LOSS>

@@ -535,7 +535,7 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
         const bool ok = i < nt;
         ls[k] = ok ? sg[base + i] : 0.0;
         lm[k] = ok ? ms[base + i] : 0.0;
-        su[i] = ok ? (u0 ? u0[base + i] : rbl::prox<LOSS>(ls[k], rho, lm[k])) : 0.0;
+        su[i] = ok ? (u0 ? u0[base + i] : rbl::prox_est<LOSS>(ls[k], rho, lm[k])) : 0.0;
         ts += ls[k];
         tm += lm[k];
     }
@@ -745,8 +745,9 @@ __global__ __launch_bounds__(PV_THREADS) void k_ehrm_fvals(long long n, const do
     for (long long i = (long long)blockIdx.x * PV_THREADS + threadIdx.x; i < n;
          i += (long long)gridDim.x * PV_THREADS) {
         const double m = ms[i];
-        double o1 = rbl::prox_bce(sa[i], rho, m);
-        double o2 = rbl::prox_bce(sb[i], rho, m);
+        const double sm = rbl::sigmoid1(m);          // shared by the two element prox problems of this position
+        double o1 = rbl::prox_bce_est(sa[i], rho, m, sm);
+        double o2 = rbl::prox_bce_est(sb[i], rho, m, sm);
         if (u0a) {
             u0a[i] = o1;
             u0b[i] = o2;
