@@ -254,7 +254,13 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     sharded = world > 1 or a.sharded_driver
+    saved_stdout = None
     if sharded:
+        # RCCL prints a version banner on stdout when its first communicator comes up: stdout carries exactly ONE
+        # JSON line (rank 0), so everything until that line is written goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29733")
         torch.cuda.set_device(local_rank)
@@ -389,7 +395,12 @@ def main():
                 out["config"]["c1"] = {"error": repr(e)[:200]}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        if saved_stdout is not None:
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        if saved_stdout is not None:
+            os.dup2(2, 1)          # whatever the teardown prints is not part of the record
     if sharded:
         dist.destroy_process_group()
 
