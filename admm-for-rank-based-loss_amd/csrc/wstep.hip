@@ -527,8 +527,11 @@ int run_ncg(const double* G, int64_t ld, const double* q, double rho, double reg
     hipLaunchKernelGGL(k_symv, dim3(sg), dim3(256), 0, s, G, (long long)ld, w, Gw, 1.0, 0.0, (const int*)nullptr);
     hipLaunchKernelGGL(k_ncg_init, dim3(1), dim3(UPD_THREADS), 0, s, (long long)ld, G, Gw, q, w, P, p, sv, gdiag, ws.scal,
                        ws.flags);
-    int batch = ws.last_fista > 0 ? ws.last_fista + ws.last_fista / 4 + 2 : 32;
-    if (batch < 8) batch = 8;
+    // one batch of about as many iterations as last time (+1): updates after convergence are no-op launches
+    // (~3.5 us each), a batch that falls short costs one more host round trip - the count moves by +-1
+    // (batch sizes +1/+2/+4 and follow-up batches of 4/8 all measured the same over 110 iterations of C2smooth)
+    int batch = ws.last_fista > 0 ? ws.last_fista + 1 : 32;
+    if (batch < 4) batch = 4;
     if (batch > 128) batch = 128;
     const int cap = max_inner < 600 ? max_inner : 600;
     int done_iters = 0, done = 0, iters = 0;
@@ -546,7 +549,7 @@ int run_ncg(const double* G, int64_t ld, const double* q, double rho, double reg
         done = st[0];
         iters = st[1];
         if (done != 0) break;
-        batch = 16;
+        batch = 4;
     }
     if (done == -1) return RBL_ERR_HIP;
     if (done == 1) {

@@ -296,6 +296,9 @@ def main():
     prof_every = 4 if a.steps >= 16 else 1
     s.profile_sampling(prof_every)
     s.reset_kernel_times()
+    import gc
+    gc.collect()
+    gc.disable()      # no collector pause inside the timed region (with N ranks the slowest one sets the pace)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -313,6 +316,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
