@@ -184,18 +184,12 @@ int alloc_sort(SortWorkspace& sw, int64_t n, bool with_vals) {
     RBL_TRY(dev_alloc(&sw.bin_base, 256));
     RBL_TRY(dev_alloc((unsigned char**)&sw.ghist, sort_ghist_bytes()));
     RBL_HIP(hipMemset(sw.ghist, 0, sort_ghist_bytes()));
-    if (sort_status_bytes(n) > 0) {
-        RBL_TRY(dev_alloc((unsigned char**)&sw.status, sort_status_bytes(n)));
-        RBL_HIP(hipMemset(sw.status, 0, sort_status_bytes(n)));   // epoch 0 never matches a sort in flight
-        sw.status_tiles = sort_tiles(n);
-    }
-    sw.epoch = 0;
     return RBL_OK;
 }
 
 void free_sort(SortWorkspace& sw) {
     dev_free(sw.keys[0]); dev_free(sw.keys[1]); dev_free(sw.vals[0]); dev_free(sw.vals[1]);
-    dev_free(sw.spine); dev_free(sw.bin_total); dev_free(sw.bin_base); dev_free(sw.status); dev_free(sw.ghist);
+    dev_free(sw.spine); dev_free(sw.bin_total); dev_free(sw.bin_base); dev_free(sw.ghist);
     sw = SortWorkspace{};
 }
 
@@ -975,7 +969,7 @@ int rbl_phase_z(rbl_solver* h, const void* m_all_dev) {
 }
 
 int rbl_phase_z_external(rbl_solver* h, const double* z) {
-    RBL_ENTER_ITER(h);
+    RBL_ENTER(h);   // a w-step enqueued ahead of time was computed for the library's own z: put w_k back
     if (!z) {
         rbl_set_error("phase_z_external: z is NULL");
         return RBL_ERR_INVALID;
@@ -1907,12 +1901,6 @@ int rbl_k_sort(int64_t n, const double* keys, double* sorted_keys, uint32_t* per
     double* ms = sc.alloc<double>((size_t)n);
     SC_CHECK(sw.keys[0] && sw.keys[1] && sw.vals[0] && sw.vals[1] && sw.spine && sw.bin_total && sw.bin_base && sw.ghist && ms);
     RBL_HIP(hipMemset(sw.ghist, 0, sort_ghist_bytes()));
-    if (sort_status_bytes(n) > 0) {
-        sw.status = (u64*)sc.alloc<unsigned char>(sort_status_bytes(n));
-        SC_CHECK(sw.status);
-        RBL_HIP(hipMemset(sw.status, 0, sort_status_bytes(n)));
-        sw.status_tiles = sort_tiles(n);
-    }
     RBL_TRY(launch_keys_from_m(n, dk, sw.keys[0], sw.vals[0], sc.s));
     RBL_TRY(launch_radix_sort(sw, n, true, sc.s));
     RBL_TRY(launch_unflip_keys(n, sw.keys[0], ms, sc.s));

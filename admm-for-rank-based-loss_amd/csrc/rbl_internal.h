@@ -105,16 +105,10 @@ struct SortWorkspace {
     u32* spine;      // 256 * RS_MAX_BLOCKS
     u32* bin_total;  // 256
     u32* bin_base;   // 256
-    // single-kernel passes (decoupled look-back): tile status words, global digit histograms / bases, tile tickets
-    u64* status;     // sort_status_bytes(n): 8 passes x tiles x 256 words; NULL = three-kernel passes
-    u32* ghist;      // 8 x 256 digit counts (zero between sorts), then 8 x 256 bases, then 8 tickets
-    u32 epoch;       // tag of the status words of the sort in flight (host side)
-    int64_t status_tiles;   // tiles the status array was sized for
+    u32* ghist;      // the spine scan's done-counter (zero between launches)
 };
 size_t sort_spine_bytes();
-size_t sort_status_bytes(int64_t n);   // 0: n too large for the single-kernel passes
 size_t sort_ghist_bytes();
-int64_t sort_tiles(int64_t n);
 // sorts keys[0]/vals[0] ascending (stable); result ends in keys[0]/vals[0]
 // key_bits: number of low key bits that can differ (digits above are skipped)
 int launch_radix_sort(SortWorkspace& ws, int64_t n, bool with_vals, hipStream_t s, int key_bits = 64);

@@ -7,16 +7,12 @@
 // Where a tile's keys go needs the digit counts of all tiles before it.  Default: three kernels
 // per pass - (1) per-block digit histogram, (2) scan of the [digit][block] spine (the block that
 // finishes last also scans the 256 digit totals), (3) scatter.
-// RBL_SORT_ONESWEEP=1 selects ONE kernel per pass instead ("onesweep", Adinets & Merrill 2022):
-// the digit histograms of all 8 passes come from one read of the input (k_rs_hist_all), and inside
-// the pass every tile publishes its digit counts and picks up its predecessors' by decoupled
-// look-back (tile order = order of arrival at a ticket counter, so a tile only ever waits for
-// tiles that are already running): 24 bytes per key and pass instead of 32, 11 launches per sort
-// instead of 24.  Measured on MI355X at 6 M keys (round 2, profiles/r02_sort_onesweep_C2sq_*):
-// 65 us per pass + 56 us up front = 574 us against 545 us - the tile kernel loses more to its
-// status traffic (2 x 256 agent-scope 8-byte stores per tile across 8 non-coherent L2s) than the
-// histogram pass costs, and batching the look-back 8 deep changes nothing.  Kept, bit-exact
-// (tests/test_gpu_kernels.py runs both), not the default.
+// A one-kernel-per-pass variant ("onesweep", Adinets & Merrill 2022: digit histograms of all passes from one
+// read, tiles pick up their predecessors' counts by decoupled look-back in ticket order) was built and
+// measured in round 2 and removed again: 65 us per pass + 56 us up front = 574 us against 545 us at 6 M keys
+// (profiles/r02_sort_onesweep_C2sq_kernel_stats.csv) - the tile kernel loses more to its status traffic
+// (2 x 256 agent-scope 8-byte stores per tile across 8 L2s that are not coherent with each other) than the
+// histogram pass costs, and batching the look-back 8 deep changed nothing.
 #include "rbl_internal.h"
 #include <cstdlib>
 
@@ -239,221 +235,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64* __restrict
 }
 
 
-// ------------------------------------------------------------------ single-kernel passes
-constexpr int OS_MAX_TILES = 16384;                 // 67 M keys; beyond: three-kernel passes
-constexpr u64 OS_VALUE_MASK = (1ull << 38) - 1;     // n < 2^32
-constexpr int OS_FLAG_SHIFT = 38, OS_EPOCH_SHIFT = 40;
-constexpr u64 OS_AGG = 1, OS_PREFIX = 2;
-
-// ghist[pass][digit] += counts of this block's keys, all passes from one read of the input.
-// The two top digits of the keys of one iteration take a handful of values (sign, exponent): their
-// counts are aggregated per wave with ballots before they touch LDS; the others are spread evenly.
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist_all(const u64* __restrict__ keys, long long n, int npass,
-                                                             u32* __restrict__ ghist) {
-    __shared__ u32 h[8][RS_BINS];
-    const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < 8 * RS_BINS; i += RS_THREADS) (&h[0][0])[i] = 0;
-    __syncthreads();
-    const long long stride = (long long)gridDim.x * RS_THREADS;
-    const long long nround = (n + stride - 1) / stride;      // every wave runs the same number of rounds (ballots)
-    for (long long r = 0; r < nround; ++r) {
-        const long long i = r * stride + (long long)blockIdx.x * RS_THREADS + tid;
-        const bool ok = i < n;
-        const u64 k = ok ? keys[i] : 0ull;
-        for (int p = 0; p < npass; ++p) {
-            const u32 dg = (u32)(k >> (8 * p)) & 0xffu;
-            if (p < 6) {
-                if (ok) atomicAdd(&h[p][dg], 1u);
-            } else {
-                u64 peers = __ballot(ok);
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const bool bit = (dg >> b) & 1u;
-                    const u64 m = __ballot(bit);
-                    peers &= bit ? m : ~m;
-                }
-                if (ok && (__ffsll((long long)peers) - 1) == lane) atomicAdd(&h[p][dg], (u32)__popcll(peers));
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < npass * RS_BINS; i += RS_THREADS) {
-        const u32 c = (&h[0][0])[i];
-        if (c) atomicAdd(&ghist[i], c);
-    }
-}
-
-// base[pass][digit] = exclusive scan of ghist[pass][.]; ghist and the tile tickets are left zero for the next sort
-__global__ __launch_bounds__(RS_BINS) void k_rs_scan_all(u32* __restrict__ ghist, int npass) {
-    __shared__ u32 wsum[RS_BINS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32* base = ghist + 8 * RS_BINS;
-    u32* ticket = ghist + 16 * RS_BINS;
-    for (int p = 0; p < npass; ++p) {
-        const u32 x = ghist[p * RS_BINS + tid];
-        u32 incl = x;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            u32 y = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += y;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        u32 b = 0;
-        for (int w = 0; w < wave; ++w) b += wsum[w];
-        base[p * RS_BINS + tid] = b + incl - x;
-        ghist[p * RS_BINS + tid] = 0;
-        __syncthreads();
-    }
-    if (tid < 8) ticket[tid] = 0;
-}
-
-// One pass: rank the tile (as k_rs_scatter does), publish its digit counts, look back, write out.
-template <bool HAS_VAL>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_onesweep(const u64* __restrict__ kin, const u32* __restrict__ vin,
-                                                             u64* __restrict__ kout, u32* __restrict__ vout,
-                                                             long long n, int shift, const u32* __restrict__ base,
-                                                             u64* status, u32* ticket, u64 epoch) {
-    __shared__ u64 skey[RS_TILE];
-    __shared__ u32 sval[HAS_VAL ? RS_TILE : 1];
-    __shared__ u32 wave_run[RS_WAVES][RS_BINS];
-    __shared__ u32 tile_start[RS_BINS];
-    __shared__ u32 glob_off[RS_BINS];
-    __shared__ u32 wsum[RS_WAVES];
-    __shared__ u32 s_tile;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);     // tile order = arrival order: predecessors are running
-    for (int i = tid; i < RS_WAVES * RS_BINS; i += RS_THREADS) (&wave_run[0][0])[i] = 0;
-    __syncthreads();
-    const long long tile = s_tile;
-    const long long tile_base = tile * RS_TILE;
-    const long long rem = n - tile_base;
-    const int tile_valid = (int)(rem < RS_TILE ? rem : RS_TILE);
-
-    u64 key[RS_ITEMS];
-    u32 val[RS_ITEMS];
-    unsigned short rank[RS_ITEMS];
-    volatile u32* myrun = wave_run[wave];
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
-        const int local = wave * (RS_TILE / RS_WAVES) + r * 64 + lane;
-        const long long gi = tile_base + local;
-        const bool ok = local < tile_valid;
-        key[r] = ok ? kin[gi] : ~0ull;  // padding sorts behind every real key of the tile
-        if (HAS_VAL) val[r] = ok ? vin[gi] : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
-        const u32 dg = digit_of(key[r], shift);
-        u64 peers = ~0ull;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (dg >> b) & 1u;
-            const u64 m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        const u32 before = (u32)__popcll(peers & lt_mask);
-        const u32 b0 = myrun[dg];
-        __builtin_amdgcn_wave_barrier();
-        if (before == 0) myrun[dg] = b0 + (u32)__popcll(peers);
-        __builtin_amdgcn_wave_barrier();
-        rank[r] = (unsigned short)(b0 + before);
-    }
-    __syncthreads();
-
-    // tile digit totals; publish them at once (successors can add them without waiting for our look-back)
-    u32 tot = 0, pre_w[RS_WAVES];
-#pragma unroll
-    for (int w = 0; w < RS_WAVES; ++w) {
-        pre_w[w] = tot;
-        tot += wave_run[w][tid];
-    }
-    u32 real = tot;                                   // padding keys (digit 255 only) are not real output
-    if (tid == RS_BINS - 1) real -= (u32)(RS_TILE - tile_valid);
-    u64* mine = status + tile * RS_BINS + tid;
-    __hip_atomic_store(mine, (epoch << OS_EPOCH_SHIFT) | ((tile == 0 ? OS_PREFIX : OS_AGG) << OS_FLAG_SHIFT) | (u64)real,
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // exclusive scan of the tile's digit totals
-    u32 incl = tot;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        u32 y = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += y;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    {
-        u32 b = 0;
-        for (int w = 0; w < wave; ++w) b += wsum[w];
-        const u32 start = b + incl - tot;
-        tile_start[tid] = start;
-#pragma unroll
-        for (int w = 0; w < RS_WAVES; ++w) wave_run[w][tid] = start + pre_w[w];
-    }
-    __syncthreads();
-    // local scatter into digit order
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
-        const u32 dg = digit_of(key[r], shift);
-        const u32 pos = wave_run[wave][dg] + rank[r];
-        skey[pos] = key[r];
-        if (HAS_VAL) sval[pos] = val[r];
-    }
-    // decoupled look-back for digit `tid`: add the counts of the tiles before this one until a tile is met that
-    // already knows its own prefix
-    // (OS_LOOK predecessors per round: their status words are loaded independently, so a round costs one
-    // memory latency instead of OS_LOOK)
-    u64 excl = 0;
-    constexpr int OS_LOOK = 8;
-    for (long long t = tile - 1; t >= 0;) {
-        u64 v[OS_LOOK];
-#pragma unroll
-        for (int j = 0; j < OS_LOOK; ++j)
-            v[j] = (t - j >= 0) ? __hip_atomic_load(status + (t - j) * RS_BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                : ((epoch << OS_EPOCH_SHIFT) | (OS_PREFIX << OS_FLAG_SHIFT));
-        int used = 0;
-        bool done = false;
-#pragma unroll
-        for (int j = 0; j < OS_LOOK; ++j) {
-            if (done || used != j) continue;
-            if ((v[j] >> OS_EPOCH_SHIFT) != epoch) continue;      // not published yet in THIS sort: poll again from here
-            excl += v[j] & OS_VALUE_MASK;
-            used = j + 1;
-            if (((v[j] >> OS_FLAG_SHIFT) & 3ull) == OS_PREFIX) done = true;
-        }
-        if (done) break;
-        t -= used;
-        if (used == 0) __builtin_amdgcn_s_sleep(2);
-    }
-    if (tile > 0)
-        __hip_atomic_store(mine, (epoch << OS_EPOCH_SHIFT) | (OS_PREFIX << OS_FLAG_SHIFT) | (excl + (u64)real), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    glob_off[tid] = base[tid] + (u32)excl;
-    __syncthreads();
-    // coalesced write-out: consecutive threads hold consecutive slots of a digit run
-#pragma unroll
-    for (int j = 0; j < RS_ITEMS; ++j) {
-        const int p = j * RS_THREADS + tid;
-        if (p < tile_valid) {
-            const u64 k = skey[p];
-            const u32 dg = digit_of(k, shift);
-            const long long dst = (long long)glob_off[dg] + (p - (int)tile_start[dg]);
-            kout[dst] = k;
-            if (HAS_VAL) vout[dst] = sval[p];
-        }
-    }
-}
-
 }  // namespace
 
-int64_t sort_tiles(int64_t n) { return (n + RS_TILE - 1) / RS_TILE; }
-size_t sort_status_bytes(int64_t n) {
-    const int64_t t = sort_tiles(n);
-    return (t < 1 || t > OS_MAX_TILES) ? 0 : (size_t)8 * (size_t)t * RS_BINS * sizeof(u64);
-}
-size_t sort_ghist_bytes() { return sizeof(u32) * (16 * RS_BINS + 16); }   // + 8 tickets + the scan's done-counter
+size_t sort_ghist_bytes() { return sizeof(u32) * 16; }   // the spine scan's done-counter
 
 size_t sort_spine_bytes() { return sizeof(u32) * RS_BINS * RS_MAX_BLOCKS; }
 
@@ -469,36 +253,6 @@ int launch_radix_sort(SortWorkspace& ws, int64_t n, bool with_vals, hipStream_t 
         rbl_set_error("radix sort: n must be < 2^32");
         return RBL_ERR_INVALID;
     }
-    static const bool onesweep = [] {
-        const char* e = getenv("RBL_SORT_ONESWEEP");
-        return e && e[0] == '1';
-    }();
-    const long long tiles = sort_tiles(n);
-    if (onesweep && ws.status && ws.ghist && tiles <= ws.status_tiles) {
-        // single-kernel passes: global digit histograms of all passes from one read, then one kernel per pass
-        ws.epoch = (ws.epoch + 1) & 0xffffffu;
-        if (ws.epoch == 0) ws.epoch = 1;
-        u32* base = ws.ghist + 8 * RS_BINS;
-        u32* ticket = ws.ghist + 16 * RS_BINS;
-        const unsigned hgrid = (unsigned)(tiles < 1024 ? tiles : 1024);
-        hipLaunchKernelGGL(k_rs_hist_all, dim3(hgrid), dim3(RS_THREADS), 0, s, ws.keys[0], (long long)n, npass, ws.ghist);
-        hipLaunchKernelGGL(k_rs_scan_all, dim3(1), dim3(RS_BINS), 0, s, ws.ghist, npass);
-        int cur = 0;
-        for (int pass = 0; pass < npass; ++pass) {
-            u64* st = ws.status + (size_t)pass * (size_t)ws.status_tiles * RS_BINS;
-            if (with_vals)
-                hipLaunchKernelGGL((k_rs_onesweep<true>), dim3((unsigned)tiles), dim3(RS_THREADS), 0, s, ws.keys[cur],
-                                   ws.vals[cur], ws.keys[cur ^ 1], ws.vals[cur ^ 1], (long long)n, pass * 8,
-                                   base + pass * RS_BINS, st, ticket + pass, (u64)ws.epoch);
-            else
-                hipLaunchKernelGGL((k_rs_onesweep<false>), dim3((unsigned)tiles), dim3(RS_THREADS), 0, s, ws.keys[cur],
-                                   (const u32*)nullptr, ws.keys[cur ^ 1], (u32*)nullptr, (long long)n, pass * 8,
-                                   base + pass * RS_BINS, st, ticket + pass, (u64)ws.epoch);
-            cur ^= 1;
-        }
-        RBL_HIP(hipGetLastError());
-        return RBL_OK;
-    }
     RsPlan p = rs_plan(n);
     int cur = 0;
     for (int pass = 0; pass < npass; ++pass) {
@@ -507,7 +261,7 @@ int launch_radix_sort(SortWorkspace& ws, int64_t n, bool with_vals, hipStream_t 
                            p.tiles_per_block, ws.spine, p.nblocks);
         if (ws.ghist) {
             hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, s, ws.spine, p.nblocks, ws.bin_total, ws.bin_base,
-                               ws.ghist + 16 * RS_BINS + 8);
+                               ws.ghist);
         } else {
             rbl_set_error("radix sort: workspace without its counter block");
             return RBL_ERR_STATE;

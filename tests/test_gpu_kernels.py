@@ -88,30 +88,6 @@ def test_sort_sorted_and_reversed(L):
             assert np.array_equal(perm, np.argsort(keys, kind="stable").astype(np.uint32))
 
 
-def test_sort_single_kernel_passes_variant():
-    """RBL_SORT_ONESWEEP=1: one kernel per pass with decoupled look-back (sort.hip) - not the default (it
-    measured slower on MI355X), but kept and therefore kept bit-exact: same checks in a process of its own."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "import admm_for_rank_based_loss_amd as rbl\n"
-        "L = rbl._lib; rng = np.random.default_rng(2)\n"
-        "for n in (1, 2, 255, 4096, 4097, 70001, 1 << 20, 3000001):\n"
-        "    keys = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4, size=n)\n"
-        "    if n > 10:\n"
-        "        keys[rng.integers(0, n, size=n // 5)] = keys[rng.integers(0, n, size=n // 5)]\n"
-        "    out, perm = L.k_sort(keys)\n"
-        "    ref = np.argsort(keys, kind='stable')\n"
-        "    assert np.array_equal(perm, ref.astype(np.uint32)), n\n"
-        "    assert np.array_equal(out.view(np.uint64), keys[ref].view(np.uint64)), n\n"
-        "print('OK')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RBL_SORT_ONESWEEP="1"), capture_output=True,
-                         text=True, timeout=300)
-    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (out.stdout[-500:], out.stderr[-1500:])
-
-
 # ------------------------------------------------------------------------------- PAV
 def test_pav_vs_oracle(L):
     from oracle import pav, weights

@@ -302,6 +302,30 @@ def test_overridden_subproblem_hooks(R, kw, d):
         z_subproblem = z_by_oracle
         w_subproblem = w_by_oracle
 
+    # a z that is NOT what the library would have computed: nothing prepared ahead of time for the library's own z
+    # (the next z-step and q of the single-sweep pass, the w-step enqueued before the host read the statistics)
+    # may survive - the run with only z overridden must equal the run in which the oracle also does the w-step
+    def z_perturbed(self):
+        return z_by_oracle(self) + 0.01 * np.cos(np.arange(n)).reshape(-1, 1)
+
+    class ZPert(R.ADMMmethod):
+        z_subproblem = z_perturbed
+
+    class BothPert(R.ADMMmethod):
+        z_subproblem = z_perturbed
+        w_subproblem = w_by_oracle
+
+    pert = []
+    for cls in (ZPert, BothPert):
+        s = cls(X, y, max_iter=nit, tol=0.0, storage="f64", **kw)
+        _quiet(s.main_loop, verbose=False)
+        pert.append((s.w.reshape(-1), s.lagrangian.reshape(-1), s._last.primal, s._last.dual))
+    ptol = 1e-8 if loss == "binary_cross_entropy" else 1e-6
+    assert np.max(np.abs(pert[0][0] - pert[1][0])) <= ptol * max(1.0, np.max(np.abs(pert[1][0])))
+    assert np.max(np.abs(pert[0][1] - pert[1][1])) <= ptol * max(1e-3, np.max(np.abs(pert[1][1])))
+    assert abs(pert[0][2] - pert[1][2]) <= ptol * max(1.0, pert[1][2]) and abs(pert[0][3] - pert[1][3]) <= ptol * max(1.0, pert[1][3])
+    assert np.max(np.abs(pert[0][0] - ref.w)) > 1e-6 * max(1.0, np.max(np.abs(ref.w)))      # the perturbation mattered
+
     tol = 1e-9 if loss == "binary_cross_entropy" else 1e-7
     for cls in (ZHook, WHook, BothHooks):
         s = cls(X, y, max_iter=nit, tol=0.0, storage="f64", **kw)
