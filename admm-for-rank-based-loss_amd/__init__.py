@@ -13,5 +13,7 @@ from . import _lib                                   # noqa: F401
 from ._solver import Solver                          # noqa: F401
 from .src.optim.algorithms import Optimizer, ADMMmethod, smoothADMMmethod   # noqa: F401
 from .src.optim.objective import rankbasedObjective, get_weights            # noqa: F401
+from .SGD_solver import SGDmethod                    # noqa: F401  (competitor baselines)
+from .LSVRG_solver import LSVRGmethod                # noqa: F401
 
-__all__ = ["ADMMmethod", "smoothADMMmethod", "Optimizer", "rankbasedObjective", "get_weights", "Solver"]
+__all__ = ["ADMMmethod", "smoothADMMmethod", "Optimizer", "rankbasedObjective", "get_weights", "Solver", "SGDmethod", "LSVRGmethod"]

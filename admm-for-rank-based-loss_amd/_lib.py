@@ -124,6 +124,13 @@ SIGNATURES = {
     "rbl_k_wstep": (C.c_int, [C.c_int, C.c_int64, _P, _P, C.c_double, C.c_double, C.c_double, _P, C.c_double, _P,
                               C.POINTER(C.c_int)]),
     "rbl_k_weights": (C.c_int, [C.c_int, C.c_int64, _P, C.c_int, _P, _P]),
+    "rbl_bl_create": (C.c_int, [C.c_int64, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                                C.POINTER(_P)]),
+    "rbl_bl_destroy": (C.c_int, [_P]),
+    "rbl_bl_set_w": (C.c_int, [_P, _P]),
+    "rbl_bl_get_w": (C.c_int, [_P, _P]),
+    "rbl_bl_sgd_epoch": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_double, _P]),
+    "rbl_bl_lsvrg_epoch": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_double, _P]),
 }
 
 _lib = None

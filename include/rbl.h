@@ -290,6 +290,31 @@ int  rbl_k_wstep(int wstep, int64_t d, const double* G, const double* q, double 
 int  rbl_k_weights(int weight_function, int64_t n, const double* args, int n_args,
                    double* alphas, double* betas);
 
+/* ---- the reference's competitor baselines ---------------------------------------------------
+ * SGDmethod (SGD_solver.py:9-96 -> StochasticSubgradientMethod, existing_methods/lerm_main/src/optim/algorithms.py:54-98)
+ * and LSVRGmethod (LSVRG_solver.py:9-98 -> LSVRG, algorithms.py:150-253) on the competitor's objective
+ * (existing_methods/lerm_main/src/optim/objective.py:41-112).  One call = one epoch.  The index and random-sign
+ * streams are the reference's own host generators (torch.randperm / numpy RandomState / numpy.random.choice /
+ * torch.rand) and are passed in as data; the Python mirrors SGD_solver.py / LSVRG_solver.py of the package draw
+ * them exactly as the reference does.  X: n x d host rows (float64), y01: labels in {0, 1} (the reference maps -1
+ * to 0 for both losses, SGD_solver.py:13-14). */
+typedef struct rbl_baseline rbl_baseline;
+int  rbl_bl_create(int64_t n, int64_t d, const double* X, const double* y01, int loss, int has_lossB, double lossB,
+                   double l2_reg, double l1_reg, int device, rbl_baseline** out);
+int  rbl_bl_destroy(rbl_baseline* h);
+int  rbl_bl_set_w(rbl_baseline* h, const double* w);
+int  rbl_bl_get_w(rbl_baseline* h, double* w);
+/* StochasticSubgradientMethod.start_epoch + `steps` x step (algorithms.py:80-93): mini-batch s = rows
+ * order[s*batch .. min(n, (s+1)*batch)); alphas_b / betas_b: the `batch`-sample weights (objective.py:72-75;
+ * betas_b NULL unless EHRM); rands: one torch.rand(1) per step for the l1 subgradient at 0 (NULL without l1_reg) */
+int  rbl_bl_sgd_epoch(rbl_baseline* h, const int32_t* order, int steps, int batch, const double* alphas_b,
+                      const double* betas_b, double lr, const float* rands);
+/* LSVRG.start_epoch + `steps` x step (algorithms.py:183-253): alphas / betas are the n-sample weights; samples[s]
+ * is a row index (uniform != 0: RandomState.randint) or a rank of the checkpoint's sorted order (uniform == 0:
+ * numpy.random.choice(n, p=alphas)) */
+int  rbl_bl_lsvrg_epoch(rbl_baseline* h, const double* alphas, const double* betas, const int32_t* samples, int steps,
+                        int uniform, double lr, const float* rands);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference; it never travels):
     python tests/golden/make_goldens.py [group ...]
-Groups: g1 g2 g3 g4 g56 g7 g8 g9 c1 table   (default: all)
+Groups: g1 g2 g3 g4 g56 g7 g8 g9 c1 table g11   (default: all)
 
 The reference snapshot has a return-shape bug (src/optim/algorithms.py:97,101 unpack
 two values, src/util/pav.py:178 and src/util/PAV_cpt.py:293 return one); the two-line
@@ -221,6 +221,51 @@ def g8():
 
 
 # ---------------------------------------------------------------- G9 trajectories
+# ------------------------------------------------------------------ G11 competitor baselines (SGD / LSVRG)
+def g11():
+    """SGDmethod (SGD_solver.py:9-96) and LSVRGmethod (LSVRG_solver.py:9-98) of the reference on small problems:
+    w after every epoch.  The global numpy / torch generators the reference draws from without seeding them
+    (np.random.choice in the non-uniform LSVRG, torch.rand for the l1 subgradient at 0) are seeded here, and the
+    seeds are part of the fixture."""
+    from SGD_solver import SGDmethod
+    from LSVRG_solver import LSVRGmethod
+    X, y = problems.make_problem(300, 10, seed=23)
+    out = {"X": X, "y": y}
+    cases = [
+        ("sgd", dict(weight_function="erm", loss="binary_cross_entropy", l2_reg=0.5, lr=0.05, max_iter=3)),
+        ("sgd", dict(weight_function="superquantile", loss="hinge", l2_reg=0.5, lr=0.05, max_iter=3, args=[0.5])),
+        ("sgd", dict(weight_function="aorr", loss="binary_cross_entropy", l2_reg=0.5, lr=0.05, max_iter=3, args=[0.2, 0.8])),
+        ("sgd", dict(weight_function="aorr_dc", loss="hinge", l2_reg=0.5, lr=0.05, max_iter=2, args=[40, 3])),
+        ("sgd", dict(weight_function="ehrm", loss="binary_cross_entropy", l2_reg=0.5, lr=0.05, max_iter=3, lossB=0.65)),
+        ("sgd", dict(weight_function="erm", loss="binary_cross_entropy", l1_reg=0.5, lr=0.05, max_iter=2)),
+        ("sgd", dict(weight_function="extremile", loss="binary_cross_entropy", l2_reg=0.5, lr=1, max_iter=2, args=[2.0],
+                     batch_size=32)),
+        ("lsvrg", dict(weight_function="superquantile", loss="binary_cross_entropy", l2_reg=0.5, lr=0.01, max_iter=3,
+                       args=[0.5], uniform=True)),
+        ("lsvrg", dict(weight_function="superquantile", loss="binary_cross_entropy", l2_reg=0.5, lr=0.01, max_iter=3,
+                       args=[0.5], uniform=None)),
+        ("lsvrg", dict(weight_function="ehrm", loss="binary_cross_entropy", l2_reg=0.5, lr=0.01, max_iter=3, lossB=0.65,
+                       uniform=True)),
+        ("lsvrg", dict(weight_function="ehrm", loss="binary_cross_entropy", l2_reg=0.5, lr=0.01, max_iter=2, lossB=0.65,
+                       uniform=None)),
+        ("lsvrg", dict(weight_function="aorr", loss="hinge", l2_reg=0.5, lr=0.01, max_iter=2, args=[0.2, 0.8], uniform=None)),
+        ("lsvrg", dict(weight_function="erm", loss="binary_cross_entropy", l1_reg=0.5, lr=0.01, max_iter=2, uniform=True)),
+    ]
+    for k, (algo, kw) in enumerate(cases):
+        ws = []
+        np.random.seed(1000 + k)          # the non-uniform LSVRG draws from the global numpy generator
+        torch.manual_seed(2000 + k)       # torch.rand of the l1 subgradient (SGD re-seeds with 25 itself)
+        fn = SGDmethod if algo == "sgd" else LSVRGmethod
+        with contextlib.redirect_stdout(io.StringIO()):
+            w, trl, tel, tarr = fn(X, y, train_loss=lambda w: ws.append(w.numpy().reshape(-1).copy()) or 0.0,
+                                   test_loss=lambda w: 0.0, verbose=False, **kw)
+        out[f"c{k}_cfg"] = json.dumps(dict(algo=algo, np_seed=1000 + k, torch_seed=2000 + k, **kw))
+        out[f"c{k}_w"] = np.array(ws)                      # (max_iter + 1, d): w0 and w after every epoch
+        print(f"  g11 case {k} {algo} {kw['weight_function']}/{kw['loss']}: |w_final| = {np.linalg.norm(w):.6f}")
+    out["ncases"] = np.array(len(cases))
+    save("g11_baselines.npz", **out)
+
+
 def run_traj(X, y, cls, kw, max_iter=200):
     buf = io.StringIO()
     t0 = time.time()
@@ -324,7 +369,7 @@ def table():
     print(f"   table: admm rows {len(rows[0])} losses / {len(rows[1])} times, final {rows[0][-1]!r}")
 
 
-GROUPS = dict(g1=g1, g2=g2, g3=g3, g4=g4, g56=g56, g7=g7, g8=g8, g9=g9, c1=c1, table=table)
+GROUPS = dict(g1=g1, g2=g2, g3=g3, g4=g4, g56=g56, g7=g7, g8=g8, g9=g9, c1=c1, table=table, g11=g11)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)
