@@ -61,45 +61,75 @@ __device__ inline double bl_reg(double wj, double l2, double l1, double n, float
     return g;
 }
 
-// one epoch of StochasticSubgradientMethod.step (algorithms.py:84-93): `steps` mini-batches of `batch` rows
+// one epoch of StochasticSubgradientMethod.step (algorithms.py:84-93): `steps` mini-batches of `batch` rows.
+// One workgroup of 16 waves; a step is latency (two dependent phases over 64 rows x d), so both phases keep
+// several independent loads in flight: a wave computes 4 logits at once, a thread accumulates its column over
+// 8 rows at a time.
+constexpr int BL_SGD_THREADS = 1024;
 template <int LOSS>
-__global__ __launch_bounds__(BL_THREADS) void k_bl_sgd_epoch(const double* __restrict__ X, long long ld, long long d,
-                                                              long long n, const double* __restrict__ y01, double* w,
-                                                              const int* __restrict__ order, int steps, int batch,
-                                                              const double* __restrict__ ab, const double* __restrict__ bb,
-                                                              int has_B, double lossB, double lr, double l2, double l1,
-                                                              const float* __restrict__ rands) {
+__global__ __launch_bounds__(BL_SGD_THREADS) void k_bl_sgd_epoch(const double* __restrict__ X, long long ld, long long d,
+                                                                  long long n, const double* __restrict__ y01, double* w,
+                                                                  const int* __restrict__ order, int steps, int batch,
+                                                                  const double* __restrict__ ab, const double* __restrict__ bb,
+                                                                  int has_B, double lossB, double lr, double l2, double l1,
+                                                                  const float* __restrict__ rands) {
     __shared__ double s_z[BL_MAX_BATCH], s_l[BL_MAX_BATCH], s_c[BL_MAX_BATCH];
-    __shared__ int s_row[BL_MAX_BATCH];
+    __shared__ long long s_off[BL_MAX_BATCH];                // row offsets into X
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = BL_SGD_THREADS / 64;
     for (int s = 0; s < steps; ++s) {
         long long b0 = (long long)s * batch, b1 = b0 + batch;
         if (b1 > n) b1 = n;
         const int b = (int)(b1 - b0);                        // rows of this mini-batch (algorithms.py:85-88)
-        if (tid < b) s_row[tid] = order[b0 + tid];
+        if (tid < b) s_off[tid] = (long long)order[b0 + tid] * ld;
         __syncthreads();
-        for (int r = wave; r < b; r += BL_THREADS / 64) {    // logits: one wave per row
-            const double* x = X + (long long)s_row[r] * ld;
-            double acc = 0.0;
-            for (long long j = lane; j < d; j += 64) acc = __builtin_fma(x[j], w[j], acc);
-            acc = rbl::wave_sum_all(acc);
-            if (lane == 0) s_z[r] = acc;
+        for (int r0 = wave * 4; r0 < b; r0 += NW * 4) {      // logits: 4 rows per wave at a time
+            const double* x0 = X + s_off[r0];
+            const double* x1 = X + s_off[r0 + 1 < b ? r0 + 1 : r0];
+            const double* x2 = X + s_off[r0 + 2 < b ? r0 + 2 : r0];
+            const double* x3 = X + s_off[r0 + 3 < b ? r0 + 3 : r0];
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            for (long long j = lane; j < d; j += 64) {
+                const double wj = w[j];
+                a0 = __builtin_fma(x0[j], wj, a0);
+                a1 = __builtin_fma(x1[j], wj, a1);
+                a2 = __builtin_fma(x2[j], wj, a2);
+                a3 = __builtin_fma(x3[j], wj, a3);
+            }
+            a0 = rbl::wave_sum_all(a0);
+            a1 = rbl::wave_sum_all(a1);
+            a2 = rbl::wave_sum_all(a2);
+            a3 = rbl::wave_sum_all(a3);
+            if (lane == 0) {
+                s_z[r0] = a0;
+                if (r0 + 1 < b) s_z[r0 + 1] = a1;
+                if (r0 + 2 < b) s_z[r0 + 2] = a2;
+                if (r0 + 3 < b) s_z[r0 + 3] = a3;
+            }
         }
         __syncthreads();
-        if (tid < b) s_l[tid] = bl_loss<LOSS>(s_z[tid], y01[s_row[tid]]);
+        if (tid < b) s_l[tid] = bl_loss<LOSS>(s_z[tid], y01[s_off[tid] / ld]);
         __syncthreads();
         if (tid < b) {
             const double lt = s_l[tid];
             int rank = 0;                                    // stable rank: ties keep the batch order
             for (int j = 0; j < b; ++j) rank += (s_l[j] < lt || (s_l[j] == lt && j < tid)) ? 1 : 0;
             const double wk = (has_B && !(lt <= lossB)) ? bb[rank] : ab[rank];   // objective.py:84-88
-            s_c[tid] = wk * bl_dloss<LOSS>(s_z[tid], y01[s_row[tid]]);
+            s_c[tid] = wk * bl_dloss<LOSS>(s_z[tid], y01[s_off[tid] / ld]);
         }
         __syncthreads();
         const float rnd = (l1 != 0.0 && rands) ? rands[s] : 0.0f;
-        for (long long j = tid; j < d; j += BL_THREADS) {
+        for (long long j = tid; j < d; j += BL_SGD_THREADS) {
             double g = 0.0;
-            for (int r = 0; r < b; ++r) g = __builtin_fma(s_c[r], X[(long long)s_row[r] * ld + j], g);
+            int r = 0;
+            for (; r + 8 <= b; r += 8) {                     // 8 independent loads in flight, summed in row order
+                double xv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xv[k] = X[s_off[r + k] + j];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g = __builtin_fma(s_c[r + k], xv[k], g);
+            }
+            for (; r < b; ++r) g = __builtin_fma(s_c[r], X[s_off[r] + j], g);
             const double wj = w[j];
             w[j] = wj - lr * (g + bl_reg(wj, l2, l1, (double)n, rnd));
         }
@@ -319,11 +349,11 @@ int rbl_bl_sgd_epoch(rbl_baseline* h, const int32_t* order, int steps, int batch
     if (betas_b) RBL_HIP(hipMemcpyAsync(h->bb, betas_b, sizeof(double) * batch, hipMemcpyHostToDevice, s));
     if (rands) RBL_HIP(hipMemcpyAsync(h->rands, rands, sizeof(float) * steps, hipMemcpyHostToDevice, s));
     if (h->loss == RBL_LOSS_BCE)
-        hipLaunchKernelGGL(k_bl_sgd_epoch<0>, dim3(1), dim3(BL_THREADS), 0, s, h->X, (long long)h->ld, (long long)h->d,
+        hipLaunchKernelGGL(k_bl_sgd_epoch<0>, dim3(1), dim3(BL_SGD_THREADS), 0, s, h->X, (long long)h->ld, (long long)h->d,
                            (long long)h->n, h->y01, h->w, h->idx, steps, batch, h->ab, h->bb, h->has_B, h->lossB, lr, h->l2, h->l1,
                            rands ? h->rands : (const float*)nullptr);
     else
-        hipLaunchKernelGGL(k_bl_sgd_epoch<1>, dim3(1), dim3(BL_THREADS), 0, s, h->X, (long long)h->ld, (long long)h->d,
+        hipLaunchKernelGGL(k_bl_sgd_epoch<1>, dim3(1), dim3(BL_SGD_THREADS), 0, s, h->X, (long long)h->ld, (long long)h->d,
                            (long long)h->n, h->y01, h->w, h->idx, steps, batch, h->ab, h->bb, h->has_B, h->lossB, lr, h->l2, h->l1,
                            rands ? h->rands : (const float*)nullptr);
     RBL_HIP(hipGetLastError());
