@@ -7,10 +7,12 @@ make_classification + preprocessing.scale + train_test_split, ``ADMMmethod`` and
 ``calculate_accuracy``.  Instead of the xlsx (openpyxl) the rows run_SRM.py:132-139 would write
 (train losses, cumulative times, test accuracy - ADMM then sADMM) go to a CSV with the same
 row order, so they can be laid beside ``table/erm_synthetic_6000x1000_l1_binary_cross_entropy.xlsx``.
-The competitor baselines (SGD / LSVRG) of the reference driver are out of scope.
+``--baselines N`` also runs the driver's three competitor calls (run_SRM.py:52-69: SGD, LSVRG with non-uniform and
+with uniform sampling, fed with the ADMM solver's two objective callbacks) for N epochs each on the device
+mirrors ``SGD_solver.SGDmethod`` / ``LSVRG_solver.LSVRGmethod`` and appends their rows in the sheet's order (:143-153).
 
     python examples/run_srm.py [--rows 10000] [--cols 1000] [--weight erm] [--loss binary_cross_entropy]
-                               [--l1 0.01 | --l2 0.01] [--args 0.5] [--out rows.csv]
+                               [--l1 0.01 | --l2 0.01] [--args 0.5] [--baselines 0] [--out rows.csv]
 """
 import argparse
 import csv
@@ -32,6 +34,7 @@ def main():
     ap.add_argument("--l2", type=float, default=None)
     ap.add_argument("--args", type=float, nargs="*", default=[0.2, 0.8])
     ap.add_argument("--out", default=None)
+    ap.add_argument("--baselines", type=int, default=0, help="epochs of SGD / LSVRG (the reference runs 1000); 0 = skip")
     ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args()
     if a.l1 is None and a.l2 is None:
@@ -40,7 +43,7 @@ def main():
     from sklearn.datasets import make_classification
     from sklearn import preprocessing
     from sklearn.model_selection import train_test_split
-    from admm_for_rank_based_loss_amd import ADMMmethod, smoothADMMmethod
+    from admm_for_rank_based_loss_amd import ADMMmethod, smoothADMMmethod, SGDmethod, LSVRGmethod
     from admm_for_rank_based_loss_amd.src.util.calculate_acc import calculate_accuracy
 
     X, label = make_classification(n_samples=a.rows, n_features=a.cols, n_classes=2, random_state=a.seed)
@@ -72,6 +75,20 @@ def main():
         print("sadmm test loss:", stest[-1])
         print("sadmm time:", stimes[-1])
         print("sadmm test acc:", sacc)
+    if a.baselines > 0:
+        # run_SRM.py:52-53: the baselines take l2_reg * n and no l1 term; their losses are logged through the ADMM
+        # solver's objectives (:57, :63, :69)
+        l2_b = a.l2 * X_train.shape[0] if a.l2 is not None else None
+        cb = dict(train_loss=admm.objective.get_arrogate_loss, test_loss=admm.test_objective.get_arrogate_loss,
+                  verbose=verbose, args=a.args)
+        for name, fn, extra in (("sgd", SGDmethod, dict(batch_size=64, lr=1e-5)),                  # :55-58
+                                ("lsvrg_nu", LSVRGmethod, dict(lr=1, uniform=None)),               # :61-64
+                                ("lsvrg_u", LSVRGmethod, dict(lr=1, uniform=True))):               # :67-70
+            bw, btrain, btest, btimes = fn(X_train, y_train, a.weight, a.loss, l2_reg=l2_b, l1_reg=None,
+                                           max_iter=a.baselines, **extra, **cb)
+            bacc = calculate_accuracy(bw.reshape(-1, 1), X_test, y_test, threshold=0.5, loss=a.loss)
+            rows += [btrain, btimes, [bacc]]
+            print(name, "train loss:", btrain[-1], "time:", btimes[-1], "test acc:", bacc)
     if a.out:
         with open(a.out, "w", newline="") as f:
             csv.writer(f).writerows(rows)

@@ -125,6 +125,40 @@ def test_run_ehrm_rows():
     assert SPD > 0.05        # the group attribute was drawn to correlate with the label
 
 
+def test_run_srm_with_competitor_rows():
+    """run_SRM.py:52-69: the three competitor calls after the ADMM solve, fed with its objective callbacks; the
+    logged losses of the SGD row equal the oracle's objective at the oracle's SGD iterates (same torch permutations)"""
+    from sklearn.datasets import make_classification
+    from sklearn import preprocessing
+    from sklearn.model_selection import train_test_split
+    from oracle import baselines, objective, weights
+    import sys
+    argv = sys.argv
+    sys.argv = ["run_srm.py", "--rows", "1500", "--cols", "30", "--weight", "superquantile", "--l2", "0.01", "--args", "0.5",
+                "--baselines", "3", "--quiet"]
+    try:
+        rows = _load("run_srm").main()
+    finally:
+        sys.argv = argv
+    assert len(rows) == 3 + 9 and all(len(rows[k]) == 4 for k in (3, 4, 6, 7, 9, 10))    # F(w0) + 3 epochs each
+    X, label = make_classification(n_samples=1500, n_features=30, n_classes=2, random_state=17)
+    label[label == 0] = -1
+    X = preprocessing.scale(X)
+    Xtr, Xte, ytr, yte = train_test_split(X, label.reshape(-1, 1), test_size=0.4, random_state=17)
+    n = Xtr.shape[0]
+    sa, _ = weights.get_weights("superquantile", n, [0.5])
+    F = lambda w: objective.objective("binary_cross_entropy", sa, Xtr, ytr, w, l2_reg=0.01)
+    hist = []
+    baselines.sgd_solve(Xtr, ytr, "superquantile", "binary_cross_entropy", l2_reg=0.01 * n, max_iter=3, batch_size=64,
+                        lr=1e-5, args=[0.5], log=lambda w: hist.append(F(w)))
+    assert np.allclose(rows[3], hist, rtol=1e-9, atol=0)
+    hist = []
+    baselines.lsvrg_solve(Xtr, ytr, "superquantile", "binary_cross_entropy", l2_reg=0.01 * n, max_iter=3, lr=1,
+                          uniform=True, args=[0.5], log=lambda w: hist.append(F(w)))
+    assert np.allclose(rows[9], hist, rtol=1e-9, atol=0)
+    assert all(0.0 <= rows[k][0] <= 1.0 for k in (5, 8, 11))
+
+
 def test_run_srm_rows():
     """run_SRM.py:21-49 call sequence (ADMM then sADMM, l1) at a reduced size"""
     from sklearn.datasets import make_classification
