@@ -38,13 +38,6 @@ __global__ __launch_bounds__(EW_THREADS) void k_erm_zc(long long n, double sigma
     (void)inv_rho;
 }
 
-__global__ void k_make_m(long long n, double rho, const double* __restrict__ v, const double* __restrict__ lam,
-                         double* __restrict__ m) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x)
-        m[i] = v[i] - lam[i] / rho;  // algorithms.py:89
-}
-
 __global__ void k_make_m_keys(long long n, double rho, const double* __restrict__ v, const double* __restrict__ lam,
                               double* __restrict__ m, u64* __restrict__ keys, u32* __restrict__ idx, u32 idx_off) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -268,13 +261,6 @@ int launch_erm_zc(int loss, int64_t n, double sigma0, double rho, const double* 
                   double* z, double* c, hipStream_t s) {
     if (n <= 0) return RBL_OK;
     LAUNCH_LOSS(k_erm_zc, loss, ew_grid(n), EW_THREADS, s, (long long)n, sigma0, rho, v, lam, m, z, c);
-    RBL_HIP(hipGetLastError());
-    return RBL_OK;
-}
-
-int launch_make_m(int64_t n, double rho, const double* v, const double* lam, double* m, hipStream_t s) {
-    if (n <= 0) return RBL_OK;
-    hipLaunchKernelGGL(k_make_m, dim3(ew_grid(n)), dim3(256), 0, s, (long long)n, rho, v, lam, m);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

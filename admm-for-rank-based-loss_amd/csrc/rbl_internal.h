@@ -73,7 +73,6 @@ int launch_standardize_negy(int storage, void* D, int64_t n, int64_t ld, int64_t
 // ---- elementwise.hip --------------------------------------------------------------------
 int launch_erm_zc(int loss, int64_t n, double sigma0, double rho, const double* v, const double* lam,
                   double* m, double* z, double* c, hipStream_t s);
-int launch_make_m(int64_t n, double rho, const double* v, const double* lam, double* m, hipStream_t s);
 // m = v - lambda/rho together with the sort's input: keys[i] = order-preserving transform of m[i], idx[i] = i + idx_off
 int launch_make_m_keys(int64_t n, double rho, const double* v, const double* lam, double* m, u64* keys, u32* idx,
                        u32 idx_off, hipStream_t s);

@@ -25,6 +25,8 @@ One-time: all-reduce of the local Gram matrices (d*d doubles) and, for generated
 the column sums.  The engine is any object with the phase methods below; ``GpuEngine``
 binds them to librbl.so, the CPU tests plug in a NumPy engine built on the oracle.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -231,6 +233,7 @@ class ShardedADMM:
     def _allreduce(self, t):
         if (self.world > 1 or self.always_allreduce) and t.numel() > 0:
             self.n_coll += 1
+            self._trace("allreduce", t.numel())
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def _allgather_rows(self, local):
@@ -249,9 +252,17 @@ class ShardedADMM:
         return self._gather[: self.e.n_total]
 
     # ------------------------------------------------------- distributed z-step (rank weights)
+    def _trace(self, *what):
+        """RBL_DIST_TRACE=<path prefix>: one line per collective and rank, flushed (debugging aid)"""
+        pre = os.environ.get("RBL_DIST_TRACE")
+        if pre:
+            with open("%s.r%d" % (pre, self.rank), "a") as f:
+                f.write(" ".join(str(w) for w in what) + "\n")
+
     def _gather_small(self, t):
         out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
         self.n_coll += 1
+        self._trace("gather", t.numel(), str(t.dtype))
         if self._stage and t.is_cuda:          # gloo moves host memory: stage (tests on one GPU only)
             h = torch.empty(out.numel(), dtype=t.dtype)
             dist.all_gather_into_tensor(h, t.contiguous().cpu(), group=self.group)
@@ -263,7 +274,9 @@ class ShardedADMM:
     def _to_host(self, t):
         """the one place the driver waits for the device"""
         self.n_sync += 1
-        return t.cpu().numpy()
+        a = t.cpu().numpy()
+        self._trace("to_host", a.tolist() if a.size <= 64 else a.size)
+        return a
 
     def _gather_counts(self, counts_dev):
         """every rank's per-destination counts (an int64 tensor that never left the device) -> the
@@ -273,6 +286,7 @@ class ShardedADMM:
     def _alltoall(self, send, send_counts, recv, recv_counts):
         sc, rc = [int(c) for c in send_counts], [int(c) for c in recv_counts]
         self.n_coll += 1
+        self._trace("alltoall", send.numel(), sc, recv.numel(), rc)
         if self._stage and send.is_cuda:       # gloo moves host memory: stage (tests on one GPU only)
             r = torch.empty(recv.numel(), dtype=recv.dtype)
             dist.all_to_all_single(r, send.cpu(), rc, sc, group=self.group)
@@ -395,6 +409,7 @@ class ShardedADMM:
     def step(self, want_objective=False):
         e = self.e
         self.n_coll = self.n_sync = 0
+        self._trace("step")
         e.phase_m()
         if e.sorted_path and self.world > 1 and self.dist_z:
             self._z_distributed()

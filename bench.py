@@ -50,6 +50,11 @@ CONFIGS = {
                     args=None, B=-5.0, label="EHRM ehrm / BCE / l2=0.01 / B=-5, synthetic 6250000x1000"),
     "C5shard": dict(rows=1_250_000, cols=10000, weight_function="erm", loss="binary_cross_entropy", wstep=1, reg=0.01,
                     args=None, B=None, label="SRM erm / BCE / l1=0.01, synthetic 1250000x10000 dense"),
+    # the 8-GPU configurations themselves (BASELINE configs[3], configs[4]): launch with --gpus 8 (rows / 8 per rank)
+    "C4": dict(rows=50_000_000, cols=1000, weight_function="ehrm", loss="binary_cross_entropy", wstep=2, reg=0.01,
+               args=None, B=-5.0, label="EHRM ehrm / BCE / l2=0.01 / B=-5, synthetic 50000000x1000 (BASELINE configs[3])"),
+    "C5": dict(rows=10_000_000, cols=10000, weight_function="erm", loss="binary_cross_entropy", wstep=1, reg=0.01,
+               args=None, B=None, label="SRM erm / BCE / l1=0.01, synthetic 10000000x10000 dense (BASELINE configs[4])"),
     "C2hinge": dict(rows=6_000_000, cols=1000, weight_function="erm", loss="hinge", wstep=1, reg=0.01,
                     args=None, B=None, label="SRM erm / hinge / l1=0.01, synthetic 6000000x1000"),
     "C2smooth": dict(rows=6_000_000, cols=1000, weight_function="erm", loss="binary_cross_entropy", wstep=3, reg=0.01,
@@ -271,6 +276,9 @@ def main():
     n_total, d = cfg["rows"], cfg["cols"]
     from admm_for_rank_based_loss_amd.dist import ShardedADMM, GpuEngine, shard_rows
     off, n_local, _ = shard_rows(n_total, world, rank)
+    if n_local * d * (4 if a.storage == "f32" else 8) > 230e9:
+        raise SystemExit(f"--config {a.config}: {n_local} x {d} rows per GPU do not fit one MI355X (288 GB): "
+                         f"launch with more GPUs (--gpus N through torch.distributed.run)")
     t_setup = time.perf_counter()
     s = rbl.Solver(n_local, d, cfg["weight_function"], cfg["loss"], reg=cfg["reg"], wstep=cfg["wstep"], B=cfg["B"],
                    args=cfg["args"], storage=a.storage, device=local_rank, n_total=n_total, row_offset=off,

@@ -33,8 +33,17 @@ def _oracle_on_device_data(s, cfg):
 
 def _run(rank, world, port, cfg, out):
     sys.path.insert(0, ROOT)
+    # a rank that stops making progress reports where it stands and exits instead of hanging the suite
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("RBL_TEST_WATCHDOG_S", "240")), exit=True)
     if world > 1:
         os.environ.update(cfg.get("env", {}))     # only the sharded run: the single-handle run stays the plain path
+        # This rig puts `world` processes on ONE GPU next to the test runner's own context.  With the HIP default of
+        # four hardware queues per process the device's queue slots are oversubscribed, and small problems (a
+        # collective every few microseconds) then stall for good in a device wait of one rank (seen with 4 ranks of
+        # n = 5 / n = 64 after in-process GPU tests; every rank on one queue: clean).  One process per GPU - the real
+        # deployment - never gets there.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
     import torch
     import torch.distributed as dist
     import admm_for_rank_based_loss_amd as rbl
