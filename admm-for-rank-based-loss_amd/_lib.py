@@ -44,7 +44,7 @@ class RblStats(C.Structure):
         ("converged", C.c_int32), ("inner_iters", C.c_int32), ("ehrm_branch", C.c_int32), ("pav_merges", C.c_int32),
         ("ms_z", C.c_float), ("ms_q", C.c_float), ("ms_w", C.c_float), ("ms_v", C.c_float), ("ms_total", C.c_float),
         ("fused", C.c_int32), ("mispredicted", C.c_int32),
-        ("fused_v", C.c_int32), ("host_syncs", C.c_int32), ("sort_passes", C.c_int32), ("reserved", C.c_int32),
+        ("fused_v", C.c_int32), ("host_syncs", C.c_int32), ("sort_passes", C.c_int32), ("zband", C.c_int32),
     ]
 
 

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <utility>
+#include <algorithm>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -102,6 +103,18 @@ struct rbl_solver {
     int eig_sweeps = 0;    // Jacobi sweeps of the one-time eigendecomposition of G (l2 w-step), 0 = CG is used
     bool keys_ready = false;   // rbl_phase_m left the sort's input (keys of m, global row ids) in sw.keys[0] / vals[0]
     int sort_passes = 0;   // radix passes executed by the z-step in flight
+    // z-step without a sort for piecewise-constant rank weights (zband.hip); `used`: this iteration's z came from it
+    // and its status word has not been looked at yet
+    struct {
+        bool checked = false, enabled = false, used = false;
+        ZbConfig cfg;
+        ZbState* st = nullptr;
+        u32* hist = nullptr;
+        double* part = nullptr;
+        int* pin = nullptr;    // pinned: [0] sequence number (written last), [1] status
+        int seq = 0, mode = 0;
+        int64_t backoff = 0, skip_until = 0;   // after an uncertified z-step the fast path pauses for 2, 4, ... 64 iterations   // mode of the iteration in flight: 0 sort, 1 banded, 2 banded then redone with the sort
+    } zb;
 };
 
 static thread_local int g_host_syncs = 0;   // one solver handle per host thread (include/rbl.h)
@@ -364,6 +377,84 @@ int z_step_sorted(rbl_solver* h, const double* msrc, double rho) {
     return RBL_OK;
 }
 
+// Are the rank weights constant on a few bands (superquantile, aorr, aorr_dc)?  Then the z-step needs no sort
+// (zband.hip).  Looked at once per handle, at the first rank-weighted z-step.
+int zb_setup(rbl_solver* h) {
+    h->zb.checked = true;
+    h->zb.enabled = false;
+    const char* off = getenv("RBL_NO_ZBAND");
+    if (off && off[0] == '1') return RBL_OK;
+    const char* mn = getenv("RBL_ZBAND_MIN_N");
+    const long long min_n = mn ? atoll(mn) : 65536;
+    if (!h->sorted_path || h->cfg.weight_function == RBL_W_EHRM || h->nt != h->n || h->n < min_n || h->n < 16) return RBL_OK;
+    constexpr int CAP = 16;
+    long long* pos_dev = nullptr;
+    int* cnt_dev = nullptr;
+    RBL_TRY(dev_alloc(&pos_dev, (size_t)CAP));
+    RBL_TRY(dev_alloc(&cnt_dev, (size_t)1));
+    int rc = launch_zb_edges(h->sigma_a, h->nt, pos_dev, cnt_dev, CAP, h->stream);
+    long long pos[CAP];
+    int cnt = 0;
+    if (rc == RBL_OK && (hipMemcpyAsync(&cnt, cnt_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                         hipMemcpyAsync(pos, pos_dev, sizeof(pos), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                         hipStreamSynchronize(h->stream) != hipSuccess))
+        rc = RBL_ERR_HIP;
+    dev_free(pos_dev);
+    dev_free(cnt_dev);
+    if (rc != RBL_OK) {
+        rbl_set_error("zband setup: reading the edges of sigma failed");
+        return rc;
+    }
+    if (cnt < 1 || cnt > ZB_MAX_BANDS - 1) return RBL_OK;   // constant weights never come here (erm); smooth families: sort
+    std::sort(pos, pos + cnt);
+    ZbConfig& c = h->zb.cfg;
+    std::memset(&c, 0, sizeof(c));
+    c.nbands = cnt + 1;
+    c.start[0] = 0;
+    for (int j = 0; j < cnt; ++j) c.start[j + 1] = pos[j];
+    c.start[c.nbands] = h->nt;
+    for (int j = 0; j < c.nbands; ++j)
+        RBL_HIP(hipMemcpy(&c.sigma[j], h->sigma_a + c.start[j], sizeof(double), hipMemcpyDeviceToHost));
+    auto size = [&](int j) { return c.start[j + 1] - c.start[j]; };
+    if (size(0) < 2 || size(c.nbands - 1) < 2) return RBL_OK;
+    // targets: last rank of every band but the last, first rank of every band but the first (ascending, unique)
+    auto add_target = [&](long long r) {
+        for (int t = 0; t < c.ntargets; ++t)
+            if (c.target_rank[t] == r) return t;
+        if (c.ntargets == ZB_MAX_TARGETS) return -1;
+        c.target_rank[c.ntargets] = r;
+        return c.ntargets++;
+    };
+    for (int j = 0; j < c.nbands; ++j) {
+        if (j > 0 && (c.first_t[j] = add_target(c.start[j])) < 0) return RBL_OK;
+        if (j < c.nbands - 1 && (c.last_t[j] = add_target(c.start[j + 1] - 1)) < 0) return RBL_OK;
+    }
+    for (int t = 1; t < c.ntargets; ++t)
+        if (c.target_rank[t] <= c.target_rank[t - 1]) return RBL_OK;   // (cannot happen: bands are disjoint and ordered)
+    // clusters: a band of two or more ranks, single-rank bands, the next band of two or more ranks
+    int L = 0;
+    for (int j = 1; j < c.nbands; ++j) {
+        if (size(j) == 1) continue;
+        if (c.nclusters == ZB_MAX_CLUSTERS) return RBL_OK;
+        bool up = false;
+        for (int q = L; q < j; ++q) up = up || c.sigma[q + 1] > c.sigma[q];
+        if (j - L > 2) return RBL_OK;   // two or more single-rank bands in a row (aorr_dc): left to the sort
+        c.cl_L[c.nclusters] = L;
+        c.cl_R[c.nclusters] = j;
+        c.cl_root[c.nclusters] = up ? 1 : 0;
+        ++c.nclusters;
+        L = j;
+    }
+    RBL_TRY(dev_alloc(&h->zb.st, (size_t)1));
+    RBL_HIP(hipMemset(h->zb.st, 0, sizeof(ZbState)));
+    RBL_TRY(dev_alloc((unsigned char**)&h->zb.hist, zb_hist_bytes()));
+    RBL_TRY(dev_alloc((unsigned char**)&h->zb.part, zb_partials_bytes()));
+    RBL_HIP(hipHostMalloc((void**)&h->zb.pin, 64, hipHostMallocDefault));
+    h->zb.pin[0] = h->zb.pin[1] = 0;
+    h->zb.enabled = true;
+    return RBL_OK;
+}
+
 // sum_i sigma_i * loss_(i) from n_total values of v (device) -> *out_dev
 int risk_from_v(rbl_solver* h, const double* v_all, double* out_dev) {
     hipStream_t s = h->stream;
@@ -408,6 +499,8 @@ int rbl_destroy(rbl_solver* h) {
     dev_free(h->zd_locx_b); dev_free(h->zd_chunk_b); dev_free(h->zd_cph_b); dev_free(h->zd_cpl_b);
     free_sort(h->sw);
     free_pav(h->pw);
+    dev_free(h->zb.st); dev_free(h->zb.hist); dev_free(h->zb.part);
+    if (h->zb.pin) (void)hipHostFree(h->zb.pin);
     dev_free(h->locx_a); dev_free(h->chunk_a); dev_free(h->cph_a); dev_free(h->cpl_a);
     dev_free(h->locx_b); dev_free(h->chunk_b); dev_free(h->cph_b); dev_free(h->cpl_b);
     free_wstep(h->ww);
@@ -962,7 +1055,19 @@ int rbl_phase_z(rbl_solver* h, const void* m_all_dev) {
             }
             msrc = h->m;
         }
-        RBL_TRY(z_step_sorted(h, msrc, rho));
+        if (!h->zb.checked) RBL_TRY(zb_setup(h));
+        h->zb.mode = 0;
+        // iteration 0 starts from w = 0, lambda = 0: every m is equal, the keys tie across every band edge
+        if (h->zb.enabled && h->keys_ready && msrc == h->m && h->iter > 0 && h->iter >= h->zb.skip_until) {
+            h->zb.seq = (h->zb.seq & 0x3fffffff) + 1;
+            h->zb.pin[0] = 0;
+            RBL_TRY(launch_zband(h->cfg.loss, h->zb.cfg, h->n, rho, h->sw.keys[0], h->m, h->z, h->zb.st, h->zb.hist,
+                                 h->zb.part, h->zb.pin, h->zb.seq, h->pw.counters, h->stream));
+            h->zb.used = true;
+            h->zb.mode = 1;
+        } else {
+            RBL_TRY(z_step_sorted(h, msrc, rho));
+        }
     }
     if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[1], h->stream));
     return RBL_OK;
@@ -1040,8 +1145,7 @@ int rbl_phase_q(rbl_solver* h) {
     return RBL_OK;
 }
 
-int rbl_phase_w(rbl_solver* h) {
-    RBL_ENTER_ITER(h);
+static int phase_w_body(rbl_solver* h) {
     const bool spec = h->spec_w;   // this w-step (and what follows it) was enqueued by the previous rbl_phase_finish
     h->spec_w = false;
     int wstep = h->cfg.wstep;
@@ -1102,6 +1206,43 @@ int rbl_phase_w(rbl_solver* h) {
     }
     if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[3], h->stream));
     return RBL_OK;
+}
+
+int rbl_phase_w(rbl_solver* h) {
+    RBL_ENTER_ITER(h);
+    RBL_TRY(phase_w_body(h));
+    if (!h->zb.used) return RBL_OK;
+    // The sort-free z-step reports through a pinned word whether it could certify its result.  The w-step's own
+    // host wait is behind us, so the word (written milliseconds earlier in stream order) is there already.
+    h->zb.used = false;
+    volatile int* pin = h->zb.pin;
+    if (pin[0] != h->zb.seq) rbl_spin_wait(pin, 0, h->stream);
+    if (pin[0] != h->zb.seq) {
+        rbl_set_error("banded z-step: its status word was never written");
+        (void)hipGetLastError();
+        return RBL_ERR_HIP;
+    }
+    if (pin[1] == ZB_OK) {
+        h->zb.backoff = 0;
+        return RBL_OK;
+    }
+    // not certified (keys tied across a band edge, a block of another shape, an unresolved bracket): this iteration's
+    // z-step, q and w-step are redone with the sort + merge-tree PAV, and the fast path pauses for 2, 4, ... 64
+    // iterations (the first iterations pool most of the rows in one block; that passes).
+    h->zb.backoff = h->zb.backoff < 2 ? 2 : (h->zb.backoff >= 32 ? 64 : 2 * h->zb.backoff);
+    h->zb.skip_until = h->iter + 1 + h->zb.backoff;
+    h->zb.mode = 2;
+    static const bool zb_debug = [] {
+        const char* e = getenv("RBL_ZBAND_DEBUG");
+        return e && e[0] == '1';
+    }();
+    if (zb_debug) fprintf(stderr, "[rbl] iteration %lld: banded z-step not certified (status %d), redone with the sort\n",
+                          (long long)h->iter, (int)pin[1]);
+    RBL_HIP(hipMemcpyAsync(h->w, h->w_prev, sizeof(double) * h->ld, hipMemcpyDeviceToDevice, h->stream));
+    RBL_TRY(z_step_sorted(h, h->m, h->step_rho));
+    RBL_TRY(launch_make_c(h->n, h->z, h->lam, h->step_rho, h->c, h->stream));
+    RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream));
+    return phase_w_body(h);
 }
 
 int rbl_phase_dual(rbl_solver* h, int want_objective) {
@@ -1307,7 +1448,7 @@ int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
         out->fused_v = h->fused_v_ran ? 1 : 0;
         out->host_syncs = g_host_syncs;    // stream waits, blocking copies and spins since the last rbl_phase_finish
         out->sort_passes = h->sorted_path ? h->sort_passes : -1;
-        out->reserved = 0;
+        out->zband = h->sorted_path ? h->zb.mode : -1;
     }
     h->rho = rho_next;
     h->iter = i + 1;

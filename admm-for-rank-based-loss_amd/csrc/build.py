@@ -11,7 +11,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "sweep.hip", "sweep_erm.hip", "elementwise.hip", "sort.hip", "pav.hip", "wstep.hip", "lasso_fs.hip", "gram.hip", "synth.hip", "eig.hip", "baselines.hip"]
+SOURCES = ["api.hip", "sweep.hip", "sweep_erm.hip", "elementwise.hip", "sort.hip", "pav.hip", "wstep.hip", "lasso_fs.hip", "gram.hip", "synth.hip", "eig.hip", "baselines.hip", "zband.hip"]
 HEADERS = ["rbl_internal.h", "device_math.h", os.path.join("..", "..", "include", "rbl.h")]
 OUT = os.path.join(HERE, "librbl.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

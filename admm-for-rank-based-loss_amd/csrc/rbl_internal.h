@@ -250,3 +250,47 @@ int launch_gram(int storage, const void* D, int64_t n, int64_t ld, int64_t d, do
 int launch_synth(int storage, void* D, int64_t n, int64_t ld, int64_t d, int64_t row_offset, u64 seed,
                  double class_sep, double flip_y, const int* colperm, const double* mix, signed char* ysign,
                  hipStream_t s);
+
+// ---- zband.hip: z-step for piecewise-constant rank weights without a sort -------------------
+constexpr int ZB_BITS = 11;          // radix-select digit (last pass: the remaining 9 bits)
+constexpr int ZB_C = 16;             // candidate block values per root pass
+constexpr int ZB_ROOT_PASSES = 8;    // bracket shrinks 15x per pass (the first one far more when the prediction is good)
+constexpr int ZB_MAX_BANDS = 8;
+constexpr int ZB_MAX_TARGETS = 12;
+constexpr int ZB_MAX_GROUPS = 6;     // distinct key prefixes among the targets in one select pass
+constexpr int ZB_MAX_CLUSTERS = 4;
+enum { ZB_OK = 0, ZB_TIE = 1, ZB_BAD = 2, ZB_GROUPS = 3, ZB_BRACKET = 4, ZB_UNRESOLVED = 5, ZB_SWALLOW_L = 6, ZB_SWALLOW_R = 7,
+       ZB_ONESIDED = 8, ZB_OVERLAP = 9 };
+
+struct ZbConfig {                        // built once from sigma (host), passed to the kernels by value
+    int nbands;
+    long long start[ZB_MAX_BANDS + 1];   // first rank of band j; start[nbands] = n
+    double sigma[ZB_MAX_BANDS];
+    int ntargets;
+    long long target_rank[ZB_MAX_TARGETS];   // ascending, unique
+    int last_t[ZB_MAX_BANDS];            // target index of band j's last rank  (j < nbands - 1)
+    int first_t[ZB_MAX_BANDS];           // target index of band j's first rank (j > 0)
+    int nclusters;                       // edge clusters: band L | single-rank bands | band R
+    int cl_L[ZB_MAX_CLUSTERS], cl_R[ZB_MAX_CLUSTERS];
+    int cl_root[ZB_MAX_CLUSTERS];        // sigma increases somewhere along the chain: pooling is possible
+};
+struct ZbState {                         // device scratch of one z-step
+    u64 prefix[ZB_MAX_TARGETS];
+    long long rem[ZB_MAX_TARGETS];
+    int group[ZB_MAX_TARGETS];
+    u64 gprefix[ZB_MAX_TARGETS];
+    u64 key[ZB_MAX_TARGETS];
+    int ngroups;
+    int status;
+    double cand[ZB_MAX_CLUSTERS][ZB_C];
+    int done[ZB_MAX_CLUSTERS];
+    int has_block[ZB_MAX_CLUSTERS];
+    double x[ZB_MAX_CLUSTERS];
+    double xh[ZB_MAX_CLUSTERS][3];        // block values of the last three certified iterations (kept across z-steps)
+    int nh[ZB_MAX_CLUSTERS];
+};
+size_t zb_hist_bytes();
+size_t zb_partials_bytes();
+int launch_zb_edges(const double* sigma, int64_t n, long long* pos, int* counter, int cap, hipStream_t s);
+int launch_zband(int loss, const ZbConfig& cfg, int64_t n, double rho, const u64* keys, const double* m, double* z,
+                 ZbState* st, u32* hist, double* partials, int* pin, int seq, u32* counters, hipStream_t s);

@@ -98,7 +98,8 @@ typedef struct rbl_stats {
     int32_t host_syncs;      /* times the host waited for the device inside this iteration's library calls
                                 (stream waits, blocking copies, the spin on the pinned statistics block) */
     int32_t sort_passes;     /* radix-sort passes the z-step executed (digits shared by all keys are skipped), -1 = n/a */
-    int32_t reserved;
+    int32_t zband;           /* rank-weighted z-step: 0 = sort + merge-tree PAV, 1 = sort-free banded path (piecewise-constant
+                                weights), 2 = banded path not certified, redone with the sort; -1 = n/a */
 } rbl_stats;
 
 typedef struct rbl_solver rbl_solver;
