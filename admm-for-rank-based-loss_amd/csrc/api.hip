@@ -106,7 +106,7 @@ struct rbl_solver {
     // z-step without a sort for piecewise-constant rank weights (zband.hip); `used`: this iteration's z came from it
     // and its status word has not been looked at yet
     struct {
-        bool checked = false, enabled = false, used = false;
+        bool checked = false, enabled = false, used = false, c_ready = false;
         ZbConfig cfg;
         ZbState* st = nullptr;
         u32* hist = nullptr;
@@ -1061,11 +1061,13 @@ int rbl_phase_z(rbl_solver* h, const void* m_all_dev) {
         if (h->zb.enabled && h->keys_ready && msrc == h->m && h->iter > 0 && h->iter >= h->zb.skip_until) {
             h->zb.seq = (h->zb.seq & 0x3fffffff) + 1;
             h->zb.pin[0] = 0;
-            RBL_TRY(launch_zband(h->cfg.loss, h->zb.cfg, h->n, rho, h->sw.keys[0], h->m, h->z, h->zb.st, h->zb.hist,
+            RBL_TRY(launch_zband(h->cfg.loss, h->zb.cfg, h->n, rho, h->sw.keys[0], h->m, h->z, h->lam, h->c, h->zb.st, h->zb.hist,
                                  h->zb.part, h->zb.pin, h->zb.seq, h->pw.counters, h->stream));
             h->zb.used = true;
+            h->zb.c_ready = true;   // the element-wise pass wrote c = z + lambda/rho as well
             h->zb.mode = 1;
         } else {
+            h->zb.c_ready = false;
             RBL_TRY(z_step_sorted(h, msrc, rho));
         }
     }
@@ -1087,6 +1089,8 @@ int rbl_phase_z_external(rbl_solver* h, const double* z) {
     // rebuild q in rbl_phase_q; erm keeps c = z + lambda/rho and ||z||^2 next to z (launch_erm_zc), rebuild both
     h->z_ready = false;
     h->keys_ready = false;
+    h->zb.used = h->zb.c_ready = false;   // whatever the library's own z-step left behind is void
+    h->zb.mode = 0;
     if (!h->sorted_path) {
         RBL_TRY(launch_make_c(h->n, h->z, h->lam, h->step_rho, h->c, h->stream));
         if (h->fused_ok) RBL_TRY(launch_sumsq(h->n, h->z, h->partials, q_zz(h), h->stream));
@@ -1129,7 +1133,8 @@ int rbl_phase_q(rbl_solver* h) {
         // rank-weighted problems: the z-step's scatter writes z alone (one random access per row); c = z +
         // lambda/rho (algorithms.py:192) is a streaming pass here.  (Forming it inside the sweep was tried:
         // the per-row division on the sweep's critical path costs 0.9 ms, the streaming pass 30 us.)
-        if (h->sorted_path) RBL_TRY(launch_make_c(h->n, h->z, h->lam, h->step_rho, h->c, h->stream));
+        if (h->sorted_path && !h->zb.c_ready) RBL_TRY(launch_make_c(h->n, h->z, h->lam, h->step_rho, h->c, h->stream));
+        h->zb.c_ready = false;
         RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream,
                              prof_now(h) ? h->kev[3] : nullptr));
         if (prof_now(h)) h->kev_pending[1] = h->n > 0;

@@ -254,7 +254,8 @@ int launch_synth(int storage, void* D, int64_t n, int64_t ld, int64_t d, int64_t
 // ---- zband.hip: z-step for piecewise-constant rank weights without a sort -------------------
 constexpr int ZB_BITS = 11;          // radix-select digit (last pass: the remaining 9 bits)
 constexpr int ZB_C = 16;             // candidate block values per root pass
-constexpr int ZB_ROOT_PASSES = 8;    // bracket shrinks 15x per pass (the first one far more when the prediction is good)
+constexpr int ZB_ROOT_PASSES = 4;    // bracket shrinks 15x per pass (the first one far more when the prediction is good)
+constexpr int ZB_GCAP = 2048;        // undecided elements the finishing kernel settles exactly
 constexpr int ZB_MAX_BANDS = 8;
 constexpr int ZB_MAX_TARGETS = 12;
 constexpr int ZB_MAX_GROUPS = 6;     // distinct key prefixes among the targets in one select pass
@@ -288,9 +289,14 @@ struct ZbState {                         // device scratch of one z-step
     double x[ZB_MAX_CLUSTERS];
     double xh[ZB_MAX_CLUSTERS][3];        // block values of the last three certified iterations (kept across z-steps)
     int nh[ZB_MAX_CLUSTERS];
+    double br[ZB_MAX_CLUSTERS][2];        // bracket of the root after the last pass
+    double frozen[ZB_MAX_CLUSTERS][4];    // outside the bracket for certain: top count / sum m, bottom count / sum m
+    double und[ZB_MAX_CLUSTERS];          // elements whose membership changes inside the bracket
+    int gcount[ZB_MAX_CLUSTERS];          // gathered so far
 };
 size_t zb_hist_bytes();
 size_t zb_partials_bytes();
 int launch_zb_edges(const double* sigma, int64_t n, long long* pos, int* counter, int cap, hipStream_t s);
+// z = the z-step, c = z + lambda/rho in the same pass
 int launch_zband(int loss, const ZbConfig& cfg, int64_t n, double rho, const u64* keys, const double* m, double* z,
-                 ZbState* st, u32* hist, double* partials, int* pin, int seq, u32* counters, hipStream_t s);
+                 const double* lam, double* c, ZbState* st, u32* hist, double* partials, int* pin, int seq, u32* counters, hipStream_t s);

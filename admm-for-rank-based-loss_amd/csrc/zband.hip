@@ -47,6 +47,8 @@ __global__ void k_zb_init(ZbState* __restrict__ st, ZbConfig cfg, u32* __restric
         st->done[t] = 0;
         st->has_block[t] = 0;
         st->x[t] = 0.0;
+        st->und[t] = 1e300;
+        st->gcount[t] = 0;
     }
     if (t == 0) {
         st->ngroups = 1;
@@ -322,6 +324,42 @@ __global__ __launch_bounds__(1024) void k_zb_scan(ZbState* __restrict__ st, ZbCo
     for (int i = threadIdx.x; i < ZB_MAX_GROUPS * ZB_BINS; i += blockDim.x) hist[i] = 0;
 }
 
+// What a certified block may look like.  A whole band may be pooled only where nothing lies beyond it (the first / the
+// last band).  With elements of both neighbouring bands the single-rank bands are inside; a block that stays on one
+// side is certified only around ONE single-rank band e: {top of L, e} needs u_e <= x, {e, bottom of R} needs u_e >= x
+// (pav.py pools e with a neighbouring block exactly then).  cT / cB: elements of L / R in the block.
+template <int LOSS>
+__device__ void zb_accept(ZbState* st, const ZbConfig& cfg, int k, double rho, double x, double cT, double cB) {
+    const int L = cfg.cl_L[k], R = cfg.cl_R[k];
+    const double sizeL = (double)(cfg.start[L + 1] - cfg.start[L]), sizeR = (double)(cfg.start[R + 1] - cfg.start[R]);
+    if (!(cT < sizeL || L == 0)) {
+        st->status = ZB_SWALLOW_L;
+        return;
+    }
+    if (!(cB < sizeR || R == cfg.nbands - 1)) {
+        st->status = ZB_SWALLOW_R;
+        return;
+    }
+    if (!(cT > 0.0 && cB > 0.0)) {
+        bool ok = false;
+        if (R - L == 2) {
+            const double ue = rbl::prox<LOSS>(cfg.sigma[L + 1], rho, rbl::unflip_key(st->key[cfg.first_t[L + 1]]));
+            ok = cT > 0.0 ? ue <= x : (cB > 0.0 ? ue >= x : true);
+        }
+        if (!ok) {
+            st->status = ZB_ONESIDED;
+            return;
+        }
+    }
+    st->x[k] = x;
+    st->xh[k][2] = st->xh[k][1];
+    st->xh[k][1] = st->xh[k][0];
+    st->xh[k][0] = x;
+    st->nh[k] = st->nh[k] < 3 ? st->nh[k] + 1 : 3;
+    st->has_block[k] = 1;
+    st->done[k] = 1;
+}
+
 // ------------------------------------------------------------------------------------------ root of psi
 // band j holds the keys in (lo_key, hi_key]
 __device__ inline void zb_band_keys(const ZbState* st, const ZbConfig& cfg, int j, u64& lo_excl, bool& has_lo, u64& hi_incl) {
@@ -335,7 +373,7 @@ template <int LOSS>
 __global__ __launch_bounds__(ZB_THREADS) void k_zb_eval(const u64* __restrict__ keys, long long n,
                                                          const ZbState* __restrict__ st, ZbConfig cfg, int k, double rho,
                                                          double* __restrict__ partials) {
-    if (st->status != ZB_OK || st->done[k]) return;
+    if (st->status != ZB_OK || st->done[k] || st->und[k] <= (double)ZB_GCAP) return;
     __shared__ double red[(ZB_THREADS / 64) * 4 * ZB_C];
     const int L = cfg.cl_L[k], R = cfg.cl_R[k];
     u64 Llo, Lhi, Rlo, Rhi;
@@ -452,7 +490,7 @@ __global__ __launch_bounds__(ZB_THREADS) void k_zb_eval(const u64* __restrict__ 
 template <int LOSS>
 __global__ __launch_bounds__(1024) void k_zb_refine(ZbState* __restrict__ st, ZbConfig cfg, int k, double rho,
                                                      const double* __restrict__ partials, int nblocks, int last) {
-    if (st->status != ZB_OK || st->done[k]) return;
+    if (st->status != ZB_OK || st->done[k] || st->und[k] <= (double)ZB_GCAP) return;
     __shared__ double tot[4 * ZB_C];
     {
         // 16 threads per value (coalesced over the 64 values): thread (v, part) sums blocks part, part + 16, ... in
@@ -529,54 +567,220 @@ __global__ __launch_bounds__(1024) void k_zb_refine(ZbState* __restrict__ st, Zb
             }
             found = true;
         } else {
+            // still undecided elements inside (a, b): remember the bracket and what lies outside of it for certain; few
+            // enough: k_zb_gather / k_zb_finish settle it exactly, otherwise the next pass subdivides the bracket
             const double a = st->cand[k][c0], b = st->cand[k][c1];
-            if (last || !(b > a)) {
-                st->status = ZB_UNRESOLVED;   // elements tied at the root (hinge plateau) or too dense for the passes
-                return;
+            st->br[k][0] = a;
+            st->br[k][1] = b;
+            st->frozen[k][0] = NT[c1];
+            st->frozen[k][1] = MT[c1];
+            st->frozen[k][2] = NB[c0];
+            st->frozen[k][3] = MB[c0];
+            st->und[k] = undecided;
+            if (undecided > (double)ZB_GCAP) {
+                if (last || !(b > a)) {
+                    st->status = ZB_UNRESOLVED;   // too many elements tied at the root (hinge plateau) or too dense
+                    return;
+                }
+                zb_candidates<LOSS>(st->cand[k], a, b);
             }
-            zb_candidates<LOSS>(st->cand[k], a, b);
         }
     }
-    if (found) {
-        // What the block may look like.  A whole band may be pooled only where nothing lies beyond it (the first /
-        // the last band).  With elements of both neighbouring bands the single-rank bands are inside; a block that stays
-        // on one side is certified only around ONE single-rank band e: {top of L, e} needs u_e <= x, {e, bottom of R}
-        // needs u_e >= x (pav.py pools e with a neighbouring block exactly then).
-        const double sizeL = (double)(cfg.start[L + 1] - cfg.start[L]), sizeR = (double)(cfg.start[R + 1] - cfg.start[R]);
-        if (!(cT < sizeL || L == 0)) {
-            st->status = ZB_SWALLOW_L;
-            return;
+    if (found) zb_accept<LOSS>(st, cfg, k, rho, x, cT, cB);
+}
+
+// ------------------------------------------------------------------------------------------ gather + finish
+// the undecided elements of the bracket (at most ZB_GCAP): their m, in any order (k_zb_finish sorts them)
+template <int LOSS>
+__global__ __launch_bounds__(ZB_THREADS) void k_zb_gather(const u64* __restrict__ keys, long long n, ZbState* __restrict__ st,
+                                                           ZbConfig cfg, int k, double rho, double* __restrict__ list) {
+    if (st->status != ZB_OK || st->done[k]) return;
+    if (st->und[k] > (double)ZB_GCAP) return;   // k_zb_finish reports it
+    const int L = cfg.cl_L[k], R = cfg.cl_R[k];
+    u64 Llo, Lhi, Rlo, Rhi;
+    bool Lhas, Rhas;
+    zb_band_keys(st, cfg, L, Llo, Lhas, Lhi);
+    zb_band_keys(st, cfg, R, Rlo, Rhas, Rhi);
+    const double a = st->br[k][0], b = st->br[k][1];
+    const double sl = cfg.sigma[L] / rho, sr = cfg.sigma[R] / rho;
+    const double tTa = zb_theta_gt<LOSS>(sl, a), tTb = zb_theta_gt<LOSS>(sl, b);   // top: in the block at a, not at b
+    const double tBa = zb_theta_lt<LOSS>(sr, a), tBb = zb_theta_lt<LOSS>(sr, b);   // bottom: in the block at b, not at a
+    auto one = [&](u64 key) {
+        bool take = false;
+        double m = 0.0;
+        if (key <= Lhi && (!Lhas || key > Llo)) {
+            m = rbl::unflip_key(key);
+            take = m > tTa && !(m > tTb);
+        } else if (key > Rlo && key <= Rhi) {
+            m = rbl::unflip_key(key);
+            take = m < tBb && !(m < tBa);
         }
-        if (!(cB < sizeR || R == cfg.nbands - 1)) {
-            st->status = ZB_SWALLOW_R;
-            return;
+        if (take) {
+            const int slot = atomicAdd(&st->gcount[k], 1);
+            if (slot < ZB_GCAP) list[(size_t)k * ZB_GCAP + slot] = m;
         }
-        if (!(cT > 0.0 && cB > 0.0)) {
-            bool ok = false;
-            if (R - L == 2) {
-                const double ue = rbl::prox<LOSS>(cfg.sigma[L + 1], rho, rbl::unflip_key(st->key[cfg.first_t[L + 1]]));
-                ok = cT > 0.0 ? ue <= x : (cB > 0.0 ? ue >= x : true);
-            }
-            if (!ok) {
-                st->status = ZB_ONESIDED;
-                return;
-            }
-        }
-        st->x[k] = x;
-        st->xh[k][2] = st->xh[k][1];
-        st->xh[k][1] = st->xh[k][0];
-        st->xh[k][0] = x;
-        st->nh[k] = st->nh[k] < 3 ? st->nh[k] + 1 : 3;
-        st->has_block[k] = 1;
-        st->done[k] = 1;
+    };
+    const long long n4 = n >> 2;
+    const ulonglong2* __restrict__ k2 = reinterpret_cast<const ulonglong2*>(keys);
+    const long long stride = (long long)gridDim.x * ZB_THREADS;
+    for (long long i = (long long)blockIdx.x * ZB_THREADS + threadIdx.x; i < n4; i += stride) {
+        const ulonglong2 p = k2[2 * i], q = k2[2 * i + 1];
+        one(p.x);
+        one(p.y);
+        one(q.x);
+        one(q.y);
     }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) one(keys[4 * n4 + threadIdx.x]);
+}
+
+// inclusive scan of v[0 .. ZB_GCAP) in LDS, 2 entries per thread, fixed order
+__device__ inline void zb_block_scan(double* v, double* wsum) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const double a = v[2 * t], b = a + v[2 * t + 1];
+    double incl = b;
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    double base = 0.0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    const double excl = base + (incl - b);
+    v[2 * t] = excl + a;
+    v[2 * t + 1] = excl + b;
+    __syncthreads();
+}
+
+// one block: the undecided elements sorted by their prox value, psi at every one of them from prefix sums, the block
+template <int LOSS>
+__global__ __launch_bounds__(1024) void k_zb_finish(ZbState* __restrict__ st, ZbConfig cfg, int k, double rho,
+                                                     const double* __restrict__ list) {
+    static_assert(ZB_GCAP == 2048, "two entries per thread of a 1024-thread block");
+    if (st->status != ZB_OK || st->done[k]) return;
+    __shared__ double su[ZB_GCAP], sm[ZB_GCAP], pTc[ZB_GCAP], pTm[ZB_GCAP], pBc[ZB_GCAP], pBm[ZB_GCAP];
+    __shared__ double wsum[16];
+    __shared__ int pstar;
+    const int t = threadIdx.x;
+    const int cnt = st->gcount[k];
+    if (st->und[k] > (double)ZB_GCAP || cnt > ZB_GCAP || (double)cnt != st->und[k]) {
+        if (t == 0) st->status = st->und[k] > (double)ZB_GCAP ? ZB_UNRESOLVED : ZB_BAD;
+        return;
+    }
+    const int L = cfg.cl_L[k], R = cfg.cl_R[k];
+    const double sL = cfg.sigma[L], sR = cfg.sigma[R];
+    const double mLhi = rbl::unflip_key(st->key[cfg.last_t[L]]);   // m <= mLhi: an element of band L (top side)
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    for (int i = t; i < ZB_GCAP; i += 1024) {
+        double m = 0.0, u = inf;
+        if (i < cnt) {
+            m = list[(size_t)k * ZB_GCAP + i];
+            u = rbl::prox<LOSS>(m <= mLhi ? sL : sR, rho, m);
+        }
+        su[i] = u;
+        sm[i] = m;
+    }
+    if (t == 0) pstar = ZB_GCAP;
+    __syncthreads();
+    // bitonic sort by (u, m) of the first N >= cnt entries (the rest is +inf already): the gather order is arbitrary,
+    // the sums below must not depend on it
+    int N = 2;
+    while (N < cnt) N <<= 1;
+    for (int size = 2; size <= N; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (2 * t < N) {
+                const int i = 2 * t - (t & (stride - 1));   // lower index of this thread's pair
+                const int j = i + stride;
+                const bool up = (i & size) == 0;
+                const double ui = su[i], uj = su[j], mi = sm[i], mj = sm[j];
+                const bool gt = ui > uj || (ui == uj && mi > mj);
+                if (gt == up) {
+                    su[i] = uj;
+                    su[j] = ui;
+                    sm[i] = mj;
+                    sm[j] = mi;
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = t; i < ZB_GCAP; i += 1024) {
+        const bool valid = i < cnt, top = valid && sm[i] <= mLhi, bot = valid && !top;
+        pTc[i] = top ? 1.0 : 0.0;
+        pTm[i] = top ? sm[i] : 0.0;
+        pBc[i] = bot ? 1.0 : 0.0;
+        pBm[i] = bot ? sm[i] : 0.0;
+    }
+    __syncthreads();
+    zb_block_scan(pTc, wsum);
+    zb_block_scan(pTm, wsum);
+    zb_block_scan(pBc, wsum);
+    zb_block_scan(pBm, wsum);
+    double At = 0.0, Mt = 0.0, nt = 0.0;
+    for (int j = L + 1; j < R; ++j) {
+        At += cfg.sigma[j];
+        Mt += rbl::unflip_key(st->key[cfg.first_t[j]]);
+        nt += 1.0;
+    }
+    const double fTc = st->frozen[k][0], fTm = st->frozen[k][1], fBc = st->frozen[k][2], fBm = st->frozen[k][3];
+    const double totTc = cnt ? pTc[cnt - 1] : 0.0, totTm = cnt ? pTm[cnt - 1] : 0.0;
+    // psi at x = su[p]: top entries with u > x (behind p's group of equal u), bottom entries with u < x (before the group)
+    auto sets_at = [&](int p, bool with_group, double& cT, double& mT, double& cB, double& mB) {
+        int lo = p, hi = p;
+        while (lo > 0 && su[lo - 1] == su[p]) --lo;
+        while (hi + 1 < cnt && su[hi + 1] == su[p]) ++hi;
+        const int tfrom = with_group ? lo : hi + 1;   // top entries at positions >= tfrom
+        cT = fTc + totTc - (tfrom > 0 ? pTc[tfrom - 1] : 0.0);
+        mT = fTm + totTm - (tfrom > 0 ? pTm[tfrom - 1] : 0.0);
+        cB = fBc + (lo > 0 ? pBc[lo - 1] : 0.0);
+        mB = fBm + (lo > 0 ? pBm[lo - 1] : 0.0);
+        return lo;
+    };
+    for (int p = t; p < cnt; p += 1024) {
+        double cT, mT, cB, mB;
+        sets_at(p, false, cT, mT, cB, mB);
+        const double psi = zb_psi<LOSS>(sL * cT + At + sR * cB, mT + Mt + mB, cT + nt + cB, rho, su[p]);
+        if (psi >= 0.0) atomicMin(&pstar, p);
+    }
+    __syncthreads();
+    if (t != 0) return;
+    const double a = st->br[k][0], b = st->br[k][1];
+    double x, cT, mT, cB, mB, lo_x, hi_x;
+    if (pstar == ZB_GCAP) {
+        // psi < 0 at every undecided element: the root lies behind the last one - no top entry, every bottom entry
+        cT = fTc;
+        mT = fTm;
+        cB = fBc + (cnt ? pBc[cnt - 1] : 0.0);
+        mB = fBm + (cnt ? pBm[cnt - 1] : 0.0);
+        lo_x = cnt ? su[cnt - 1] : a;
+        hi_x = b;
+        x = zb_block_value<LOSS>(sL * cT + At + sR * cB, mT + Mt + mB, cT + nt + cB, rho);
+    } else {
+        const int p = pstar;
+        sets_at(p, false, cT, mT, cB, mB);
+        if (zb_psi<LOSS>(sL * cT + At + sR * cB, mT + Mt + mB, cT + nt + cB, rho, su[p]) == 0.0) {
+            x = lo_x = hi_x = su[p];
+        } else {
+            // the root lies before su[p]: the group at su[p] is still part of the top side, nothing of it of the bottom side
+            const int lo = sets_at(p, true, cT, mT, cB, mB);
+            lo_x = lo > 0 ? su[lo - 1] : a;
+            hi_x = su[p];
+            x = zb_block_value<LOSS>(sL * cT + At + sR * cB, mT + Mt + mB, cT + nt + cB, rho);
+        }
+    }
+    // (closed interval: a hinge block on the plateau returns exactly -1, the value its tied elements sit at)
+    if (!(x >= lo_x && x <= hi_x && x >= a && x <= b)) {
+        st->status = ZB_BRACKET;
+        return;
+    }
+    zb_accept<LOSS>(st, cfg, k, rho, x, cT, cB);
 }
 
 // ------------------------------------------------------------------------------------------ apply
 template <int LOSS>
 __global__ __launch_bounds__(ZB_THREADS) void k_zb_apply(const double* __restrict__ m, long long n,
                                                           const ZbState* __restrict__ st, ZbConfig cfg, double rho,
-                                                          double* __restrict__ z, int* __restrict__ pin, int seq,
+                                                          double* __restrict__ z, const double* __restrict__ lam,
+                                                          double* __restrict__ c, int* __restrict__ pin, int seq,
                                                           u32* __restrict__ counters) {
     __shared__ u64 bhi[ZB_MAX_BANDS];
     __shared__ double lo[ZB_MAX_BANDS], hi[ZB_MAX_BANDS], mlo[ZB_MAX_BANDS], mhi[ZB_MAX_BANDS], sg[ZB_MAX_BANDS];
@@ -629,18 +833,27 @@ __global__ __launch_bounds__(ZB_THREADS) void k_zb_apply(const double* __restric
         if (mi < mlo[j]) return lo[j];
         return fmin(fmax(sg[j] == 0.0 ? mi : rbl::prox_est<LOSS>(sg[j], rho, mi), lo[j]), hi[j]);
     };
+    // z and, in the same pass, c = z + lambda/rho (algorithms.py:192; the sorted path forms it in rbl_phase_q)
     const long long n2 = n >> 1;
     const double2* __restrict__ m2 = reinterpret_cast<const double2*>(m);
+    const double2* __restrict__ l2 = reinterpret_cast<const double2*>(lam);
     double2* __restrict__ z2 = reinterpret_cast<double2*>(z);
+    double2* __restrict__ c2 = reinterpret_cast<double2*>(c);
     const long long stride = (long long)gridDim.x * ZB_THREADS;
     for (long long i = (long long)blockIdx.x * ZB_THREADS + threadIdx.x; i < n2; i += stride) {
-        const double2 v = m2[i];
-        double2 r;
+        const double2 v = m2[i], l = l2[i];
+        double2 r, cc;
         r.x = one(v.x);
         r.y = one(v.y);
+        cc.x = r.x + l.x / rho;
+        cc.y = r.y + l.y / rho;
         z2[i] = r;
+        c2[i] = cc;
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) z[n - 1] = one(m[n - 1]);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        z[n - 1] = one(m[n - 1]);
+        c[n - 1] = z[n - 1] + lam[n - 1] / rho;
+    }
 }
 
 // positions where sigma changes (setup)
@@ -664,7 +877,8 @@ static int zb_hist_blocks(int64_t n) {
     const int64_t b = (n + ZB_HTHREADS * 8 - 1) / (ZB_HTHREADS * 8);
     return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
 }
-size_t zb_partials_bytes() { return sizeof(double) * 1024 * 4 * ZB_C; }
+// eval partials (512 blocks x 64 values) followed by the gather lists of the clusters
+size_t zb_partials_bytes() { return sizeof(double) * (1024 * 4 * ZB_C + ZB_MAX_CLUSTERS * ZB_GCAP); }
 
 int launch_zb_edges(const double* sigma, int64_t n, long long* pos, int* counter, int cap, hipStream_t s) {
     RBL_HIP(hipMemsetAsync(counter, 0, sizeof(int), s));
@@ -678,9 +892,10 @@ int launch_zb_edges(const double* sigma, int64_t n, long long* pos, int* counter
 
 // the whole banded z-step: keys (of m, any payload) -> z in row order; the status lands in pin[1] with pin[0] = seq
 int launch_zband(int loss, const ZbConfig& cfg, int64_t n, double rho, const u64* keys, const double* m, double* z,
-                 ZbState* st, u32* hist, double* partials, int* pin, int seq, u32* counters, hipStream_t s) {
+                 const double* lam, double* c, ZbState* st, u32* hist, double* partials, int* pin, int seq, u32* counters, hipStream_t s) {
     hipLaunchKernelGGL(k_zb_init, dim3(1), dim3(1024), 0, s, st, cfg, hist);
     const int hb = zb_eval_blocks(n), sb = zb_hist_blocks(n);
+    double* glist = partials + 1024 * 4 * ZB_C;
     for (int pass = 0; pass < 6; ++pass) {
         hipLaunchKernelGGL(k_zb_hist, dim3(sb), dim3(ZB_HTHREADS), 0, s, keys, (long long)n, (const ZbState*)st, hist, pass);
         if (loss == RBL_LOSS_BCE)
@@ -702,15 +917,22 @@ int launch_zband(int loss, const ZbConfig& cfg, int64_t n, double rho, const u64
                 hipLaunchKernelGGL(k_zb_refine<1>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)partials, hb, last);
             }
         }
+        if (loss == RBL_LOSS_BCE) {
+            hipLaunchKernelGGL(k_zb_gather<0>, dim3(hb), dim3(ZB_THREADS), 0, s, keys, (long long)n, st, cfg, k, rho, glist);
+            hipLaunchKernelGGL(k_zb_finish<0>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)glist);
+        } else {
+            hipLaunchKernelGGL(k_zb_gather<1>, dim3(hb), dim3(ZB_THREADS), 0, s, keys, (long long)n, st, cfg, k, rho, glist);
+            hipLaunchKernelGGL(k_zb_finish<1>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)glist);
+        }
     }
     const int64_t ab = (n + ZB_THREADS * 8 - 1) / (ZB_THREADS * 8);
     const unsigned ag = (unsigned)(ab < 1 ? 1 : (ab > 2048 ? 2048 : ab));
     if (loss == RBL_LOSS_BCE)
-        hipLaunchKernelGGL(k_zb_apply<0>, dim3(ag), dim3(ZB_THREADS), 0, s, m, (long long)n, (const ZbState*)st, cfg, rho, z, pin, seq,
-                           counters);
+        hipLaunchKernelGGL(k_zb_apply<0>, dim3(ag), dim3(ZB_THREADS), 0, s, m, (long long)n, (const ZbState*)st, cfg, rho, z, lam, c, pin,
+                           seq, counters);
     else
-        hipLaunchKernelGGL(k_zb_apply<1>, dim3(ag), dim3(ZB_THREADS), 0, s, m, (long long)n, (const ZbState*)st, cfg, rho, z, pin, seq,
-                           counters);
+        hipLaunchKernelGGL(k_zb_apply<1>, dim3(ag), dim3(ZB_THREADS), 0, s, m, (long long)n, (const ZbState*)st, cfg, rho, z, lam, c, pin,
+                           seq, counters);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

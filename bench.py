@@ -312,7 +312,7 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     last = None
-    n_fused = n_mispred = n_coll = n_drv_sync = n_lib_sync = 0
+    n_fused = n_mispred = n_coll = n_drv_sync = n_lib_sync = n_zband = n_zredo = 0
     for _ in range(a.steps):
         last = step()
         n_fused += int(last.fused)
@@ -320,6 +320,8 @@ def main():
         n_coll += int(getattr(last, "collectives", 0))          # set by the multi-GPU driver (dist.py)
         n_drv_sync += int(getattr(last, "driver_syncs", 0))
         n_lib_sync += int(last.host_syncs)
+        n_zband += int(last.zband == 1)
+        n_zredo += int(last.zband == 2)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -368,6 +370,7 @@ def main():
                            "z": round(last.ms_z, 3), "q": round(last.ms_q, 3), "w": round(last.ms_w, 3),
                            "v": round(last.ms_v, 3), "total": round(last.ms_total, 3)} if a.phase_times else None),
                        "single_sweep_iterations": n_fused, "rho_mispredictions": n_mispred,
+                       "sort_free_z_steps": n_zband, "sort_free_z_steps_redone": n_zredo,
                        # how an iteration talks (rank 0): collectives issued by the multi-GPU driver, its host
                        # waits (device -> host reads of count / bound vectors) and the library's own (the
                        # pinned statistics block, the w-step's status word)

@@ -1,0 +1,53 @@
+"""Randomised runner for the sort-free banded z-step (csrc/zband.hip): random sizes, rank fractions, losses, w-steps and
+seeds; every trial runs the same device-generated problem twice - fast path off (sort + merge-tree PAV) and on - and
+compares the iterates after every iteration.  Not collected by pytest:  python tests/stress_zband.py [trials] [seed]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import admm_for_rank_based_loss_amd as rbl
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+os.environ["RBL_ZBAND_MIN_N"] = "16"
+worst, used, total, redone = 0.0, 0, 0, 0
+t0 = time.time()
+for trial in range(trials):
+    n = int(rng.choice([200, 1000, 5000, 20011, 60000, 150000]))
+    d = int(rng.choice([3, 8, 24, 65]))
+    loss = str(rng.choice(["binary_cross_entropy", "hinge"]))
+    wstep = int(rng.choice([1, 2]))
+    if rng.random() < 0.5:
+        wf, args = "superquantile", [float(rng.choice([0.5, 0.9, 0.1, round(float(rng.uniform(0.05, 0.95)), 3)]))]
+    else:
+        lo = float(rng.uniform(0.02, 0.6))
+        wf, args = "aorr", [round(lo, 3), round(float(rng.uniform(lo + 0.1, 0.99)), 3)]
+    reg = float(rng.choice([1e-4, 0.01, 1.0]))
+    seed = int(rng.integers(1, 10_000))
+    nit = int(rng.choice([8, 25, 60]))
+    storage = str(rng.choice(["f64", "f32"]))
+    runs = []
+    for off in ("1", "0"):
+        os.environ["RBL_NO_ZBAND"] = off
+        s = rbl.Solver(n, d, wf, loss, reg=reg, wstep=wstep, args=args, tol=0.0, storage=storage)
+        s.generate_synthetic(seed=seed)
+        hist, modes = [], []
+        for _ in range(nit):
+            st = s.step(True)
+            hist.append((st.primal, st.dual, st.objective))
+            modes.append(st.zband)
+        runs.append((np.array(hist), s.get_state(), modes))
+    (ha, a, ma), (hb, b, mb) = runs
+    tol = 1e-8 if loss == "binary_cross_entropy" else 1e-6
+    ew = float(np.max(np.abs(a["w"] - b["w"])) / max(1.0, np.max(np.abs(a["w"]))))
+    ez = float(np.max(np.abs(a["z"] - b["z"])) / max(1.0, np.max(np.abs(a["z"]))))
+    eh = float(np.max(np.abs(ha - hb) / np.maximum(1.0, np.abs(ha))))
+    worst = max(worst, ew, ez, eh)
+    used += mb.count(1); redone += mb.count(2); total += len(mb)
+    ok = ew <= tol and ez <= 10 * tol and eh <= tol and set(ma) == {0}
+    print(f"trial {trial:3d} n={n:6d} d={d:2d} {wf}{args} {loss[:5]} {storage} wstep={wstep} reg={reg:g} its={nit:2d} "
+          f"modes 1:{mb.count(1)} 2:{mb.count(2)} 0:{mb.count(0)}  dw={ew:.1e} dz={ez:.1e} dh={eh:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
+    if not ok:
+        print("modes:", "".join(map(str, mb)))
+        sys.exit(1)
+print(f"{trials} trials clean in {time.time() - t0:.0f} s: fast path on {used}/{total} iterations, redone {redone}, worst relative difference {worst:.2e}")
