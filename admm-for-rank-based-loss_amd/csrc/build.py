@@ -36,7 +36,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + os.environ.get("RBL_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]   # (extra flags: kernel experiments)
         r = subprocess.run(cmd, capture_output=True, text=True)
         return job, r
 

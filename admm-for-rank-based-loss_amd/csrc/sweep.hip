@@ -41,6 +41,30 @@ template <> struct Pkt<double> {
     }
 };
 
+// D is streamed once per pass and is far larger than L2 + MALL: the loads carry the non-temporal hint (measured on
+// MI355X: +8 % on the single-sweep kernel; RBL_D_STREAM=0 at compile time restores plain loads)
+#ifndef RBL_D_STREAM
+#define RBL_D_STREAM 1
+#endif
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+__device__ inline float4 ld_stream(const float4* p) {
+#if RBL_D_STREAM
+    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ inline double2 ld_stream(const double2* p) {
+#if RBL_D_STREAM
+    const f64x2_t v = __builtin_nontemporal_load(reinterpret_cast<const f64x2_t*>(p));
+    return make_double2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+
 __device__ inline double shfl_xor_d(double x, int mask) {
     return __shfl_xor(x, mask, 64);
 }
@@ -93,7 +117,7 @@ __global__ __launch_bounds__(256) void k_gemv(const T* __restrict__ D, long long
                 long long pk = sub + (long long)p * LPR;
                 if (pk >= PK) pk = PK - 1;  // tail lanes re-read the last packet with w == 0
 #pragma unroll
-                for (int u = 0; u < U; ++u) buf[u][p] = rowp[u][pk];
+                for (int u = 0; u < U; ++u) buf[u][p] = ld_stream(rowp[u] + pk);
             }
 #pragma unroll
             for (int p = 0; p < (P > 0 ? P : 1); ++p)
@@ -109,7 +133,7 @@ __global__ __launch_bounds__(256) void k_gemv(const T* __restrict__ D, long long
 #pragma unroll
                 for (int b = 0; b < PB; ++b)
 #pragma unroll
-                    for (int u = 0; u < U; ++u) x[b][u] = rowp[u][pk + (long long)b * LPR];
+                    for (int u = 0; u < U; ++u) x[b][u] = ld_stream(rowp[u] + pk + (long long)b * LPR);
 #pragma unroll
                 for (int b = 0; b < PB; ++b) {
                     const double* wp = sw + (pk + (long long)b * LPR) * E;
@@ -121,7 +145,7 @@ __global__ __launch_bounds__(256) void k_gemv(const T* __restrict__ D, long long
                 const double* wp = sw + pk * E;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    pkt_t x = rowp[u][pk];
+                    pkt_t x = ld_stream(rowp[u] + pk);
                     Pkt<T>::fma(x, wp, acc[u]);
                 }
             }
@@ -242,7 +266,7 @@ __global__ __launch_bounds__(256) void k_gemvt(const T* __restrict__ D, long lon
             cv[u] = ok ? (c ? c[r] : 1.0) : 0.0;
             const pkt_t* rp = reinterpret_cast<const pkt_t*>(D + r * ld);
 #pragma unroll
-            for (int j = 0; j < PJ; ++j) buf[u][j] = rp[pk[j]];
+            for (int j = 0; j < PJ; ++j) buf[u][j] = ld_stream(rp + pk[j]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)

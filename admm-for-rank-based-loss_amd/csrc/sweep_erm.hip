@@ -20,6 +20,9 @@
 // simply recomputes the z-step / q with the unfused kernels (api.hip).
 // Algorithmic bytes = n*ld*sizeof(T): half of the unfused iteration's.
 #include "rbl_internal.h"
+#ifndef RBL_D_AUX
+#define RBL_D_AUX 2   // cache policy of the streaming loads of D: 2 = nt (non-temporal) on gfx950; 0 = default policy
+#endif
 #include "device_math.h"
 
 namespace {
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
             const __amdgpu_buffer_rsrc_t rs =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(D + row * ld), 0, (int)row_bytes, 0x00020000);
 #pragma unroll
-            for (int p = 0; p < P; ++p) buf[r][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[p], 0, 0);
+            for (int p = 0; p < P; ++p) buf[r][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[p], 0, RBL_D_AUX);
         }
     };
 
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(SEW_THREADS, 1) void k_sweep_erm_wide(
             const __amdgpu_buffer_rsrc_t rs =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(D + row * ld), 0, (int)row_bytes, 0x00020000);
 #pragma unroll
-            for (int p = 0; p < PT; ++p) buf[r][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[p], 0, 0);
+            for (int p = 0; p < PT; ++p) buf[r][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[p], 0, RBL_D_AUX);
         }
     };
 
