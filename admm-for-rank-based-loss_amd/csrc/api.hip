@@ -462,6 +462,9 @@ int risk_from_v(rbl_solver* h, const double* v_all, double* out_dev) {
         return launch_loss_sum(h->cfg.loss, h->nt, v_all, 1.0 / (double)h->nt, h->partials, out_dev, s);
     h->keys_ready = false;   // the sort workspace is reused: keys left by rbl_phase_m are gone
     RBL_TRY(launch_loss_keys(h->nt, v_all, h->sw.keys[0], s));
+    // piecewise-constant weights: the band sums of the losses need a select, not a sort (zband.hip; exact for any v)
+    if (h->zb.enabled)
+        return launch_zband_risk(h->cfg.loss, h->zb.cfg, h->nt, h->sw.keys[0], h->zb.st, h->zb.hist, h->zb.part, out_dev, s);
     RBL_TRY(launch_radix_sort(h->sw, h->nt, false, s));
     return launch_sorted_loss_dot(h->cfg.loss, h->nt, h->sw.keys[0], h->sigma_a, h->partials, out_dev, s);
 }

@@ -281,6 +281,7 @@ struct ZbState {                         // device scratch of one z-step
     int group[ZB_MAX_TARGETS];
     u64 gprefix[ZB_MAX_TARGETS];
     u64 key[ZB_MAX_TARGETS];
+    long long eq[ZB_MAX_TARGETS];         // keys equal to key[t] (rem[t] ends as the target's rank among them)
     int ngroups;
     int status;
     double cand[ZB_MAX_CLUSTERS][ZB_C];
@@ -300,3 +301,5 @@ int launch_zb_edges(const double* sigma, int64_t n, long long* pos, int* counter
 // z = the z-step, c = z + lambda/rho in the same pass
 int launch_zband(int loss, const ZbConfig& cfg, int64_t n, double rho, const u64* keys, const double* m, double* z,
                  const double* lam, double* c, ZbState* st, u32* hist, double* partials, int* pin, int seq, u32* counters, hipStream_t s);
+int launch_zband_risk(int loss, const ZbConfig& cfg, int64_t n, const u64* keys, ZbState* st, u32* hist, double* partials,
+                      double* out_dev, hipStream_t s);

@@ -251,7 +251,7 @@ __device__ void zb_cluster_setup(ZbState* st, const ZbConfig& cfg, double rho) {
 // one block: the digit of every target inside its bucket, new prefixes, regrouping; clears the histogram
 template <int LOSS>
 __global__ __launch_bounds__(1024) void k_zb_scan(ZbState* __restrict__ st, ZbConfig cfg, u32* __restrict__ hist, int pass,
-                                                   double rho) {
+                                                   double rho, int zstep) {
     __shared__ u64 newp[ZB_MAX_TARGETS];
     __shared__ long long newr[ZB_MAX_TARGETS];
     __shared__ int bad;
@@ -290,6 +290,7 @@ __global__ __launch_bounds__(1024) void k_zb_scan(ZbState* __restrict__ st, ZbCo
             }
             newp[t] = (st->prefix[t] << bits) | (u64)bin;
             newr[t] = r - cum;
+            if (pass == 5) st->eq[t] = hg[bin];   // keys equal to the target's key; newr = the target's rank among them
         }
     }
     __syncthreads();
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(1024) void k_zb_scan(ZbState* __restrict__ st, ZbCo
             st->ngroups = G;
             if (pass == 5 && st->status == ZB_OK) {
                 for (int t = 0; t < cfg.ntargets; ++t) st->key[t] = st->prefix[t];
-                zb_cluster_setup<LOSS>(st, cfg, rho);
+                if (zstep) zb_cluster_setup<LOSS>(st, cfg, rho);
             }
         }
     }
@@ -775,6 +776,100 @@ __global__ __launch_bounds__(1024) void k_zb_finish(ZbState* __restrict__ st, Zb
     zb_accept<LOSS>(st, cfg, k, rho, x, cT, cB);
 }
 
+// ------------------------------------------------------------------------------------------ objective
+// sum_k sigma_k loss(v_(k)) (objective.py:73-81) for banded sigma: the band sums of the losses need the keys at the last
+// rank of every band (the same select) and one pass; elements tied with a band-edge key are accounted for by their
+// count (their losses are equal, so which of them falls on which side of the edge does not matter).
+template <int LOSS>
+__global__ __launch_bounds__(ZB_THREADS) void k_zb_risk(const u64* __restrict__ keys, long long n, const ZbState* __restrict__ st,
+                                                         ZbConfig cfg, double* __restrict__ partials) {
+    __shared__ u64 bk[ZB_MAX_BANDS];
+    __shared__ double red[(ZB_THREADS / 64) * ZB_MAX_BANDS];
+    const int B = cfg.nbands;
+    if (threadIdx.x < B - 1) bk[threadIdx.x] = st->key[cfg.last_t[threadIdx.x]];
+    __syncthreads();
+    double acc[ZB_MAX_BANDS];
+#pragma unroll
+    for (int j = 0; j < ZB_MAX_BANDS; ++j) acc[j] = 0.0;
+    auto one = [&](u64 key) {
+        int j = 0;
+        bool tie = false;
+        for (int q = 0; q < B - 1; ++q) {
+            j += key > bk[q] ? 1 : 0;
+            tie = tie || key == bk[q];
+        }
+        if (tie) return;
+        const double l = rbl::sample_loss<LOSS>(rbl::unflip_key(key));
+#pragma unroll
+        for (int q = 0; q < ZB_MAX_BANDS; ++q) acc[q] += q == j ? l : 0.0;
+    };
+    const long long n4 = n >> 2;
+    const ulonglong2* __restrict__ k2 = reinterpret_cast<const ulonglong2*>(keys);
+    const long long stride = (long long)gridDim.x * ZB_THREADS;
+    for (long long i = (long long)blockIdx.x * ZB_THREADS + threadIdx.x; i < n4; i += stride) {
+        const ulonglong2 a = k2[2 * i], b = k2[2 * i + 1];
+        one(a.x);
+        one(a.y);
+        one(b.x);
+        one(b.y);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) one(keys[4 * n4 + threadIdx.x]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < ZB_MAX_BANDS; ++j) {
+        double a = acc[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+        if (lane == 0) red[wave * ZB_MAX_BANDS + j] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < ZB_MAX_BANDS) {
+        double s = 0.0;
+        for (int w = 0; w < ZB_THREADS / 64; ++w) s += red[w * ZB_MAX_BANDS + threadIdx.x];
+        partials[(size_t)blockIdx.x * ZB_MAX_BANDS + threadIdx.x] = s;
+    }
+}
+
+template <int LOSS>
+__global__ __launch_bounds__(256) void k_zb_risk_finish(const ZbState* __restrict__ st, ZbConfig cfg,
+                                                         const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+    __shared__ double tmp[32 * ZB_MAX_BANDS], tot[ZB_MAX_BANDS];
+    const int v = threadIdx.x & (ZB_MAX_BANDS - 1), part = threadIdx.x / ZB_MAX_BANDS;   // 32 threads per band, in order
+    double s = 0.0;
+    for (int b = part; b < nblocks; b += 32) s += partials[(size_t)b * ZB_MAX_BANDS + v];
+    tmp[part * ZB_MAX_BANDS + v] = s;
+    __syncthreads();
+    if (part == 0) {
+        double a = 0.0;
+        for (int p = 0; p < 32; ++p) a += tmp[p * ZB_MAX_BANDS + v];
+        tot[v] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double risk = 0.0;
+    for (int j = 0; j < cfg.nbands; ++j) risk += cfg.sigma[j] * tot[j];
+    // the elements tied with a band-edge key: ranks [first, first + eq) all carry the loss of that key
+    u64 prev = 0;
+    bool have_prev = false;
+    for (int j = 0; j < cfg.nbands - 1; ++j) {
+        const int t = cfg.last_t[j];
+        const u64 key = st->key[t];
+        if (have_prev && key == prev) continue;
+        prev = key;
+        have_prev = true;
+        const long long first = cfg.target_rank[t] - st->rem[t], last = first + st->eq[t];
+        const double l = rbl::sample_loss<LOSS>(rbl::unflip_key(key));
+        double wsum = 0.0;
+        for (int q = 0; q < cfg.nbands; ++q) {
+            const long long a = first > cfg.start[q] ? first : cfg.start[q];
+            const long long b = last < cfg.start[q + 1] ? last : cfg.start[q + 1];
+            if (b > a) wsum += cfg.sigma[q] * (double)(b - a);
+        }
+        risk += wsum * l;
+    }
+    out[0] = st->status == ZB_OK ? risk : __longlong_as_double(0x7ff8000000000000ll);
+}
+
 // ------------------------------------------------------------------------------------------ apply
 template <int LOSS>
 __global__ __launch_bounds__(ZB_THREADS) void k_zb_apply(const double* __restrict__ m, long long n,
@@ -899,9 +994,9 @@ int launch_zband(int loss, const ZbConfig& cfg, int64_t n, double rho, const u64
     for (int pass = 0; pass < 6; ++pass) {
         hipLaunchKernelGGL(k_zb_hist, dim3(sb), dim3(ZB_HTHREADS), 0, s, keys, (long long)n, (const ZbState*)st, hist, pass);
         if (loss == RBL_LOSS_BCE)
-            hipLaunchKernelGGL(k_zb_scan<0>, dim3(1), dim3(1024), 0, s, st, cfg, hist, pass, rho);
+            hipLaunchKernelGGL(k_zb_scan<0>, dim3(1), dim3(1024), 0, s, st, cfg, hist, pass, rho, 1);
         else
-            hipLaunchKernelGGL(k_zb_scan<1>, dim3(1), dim3(1024), 0, s, st, cfg, hist, pass, rho);
+            hipLaunchKernelGGL(k_zb_scan<1>, dim3(1), dim3(1024), 0, s, st, cfg, hist, pass, rho, 1);
     }
     for (int k = 0; k < cfg.nclusters; ++k) {
         if (!cfg.cl_root[k]) continue;
@@ -933,6 +1028,26 @@ int launch_zband(int loss, const ZbConfig& cfg, int64_t n, double rho, const u64
     else
         hipLaunchKernelGGL(k_zb_apply<1>, dim3(ag), dim3(ZB_THREADS), 0, s, m, (long long)n, (const ZbState*)st, cfg, rho, z, lam, c, pin,
                            seq, counters);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+// sum_k sigma_k loss(v_(k)) for banded sigma from the keys of v -> out_dev[0] (no sort; always exact)
+int launch_zband_risk(int loss, const ZbConfig& cfg, int64_t n, const u64* keys, ZbState* st, u32* hist, double* partials,
+                      double* out_dev, hipStream_t s) {
+    hipLaunchKernelGGL(k_zb_init, dim3(1), dim3(1024), 0, s, st, cfg, hist);
+    const int hb = zb_eval_blocks(n), sb = zb_hist_blocks(n);
+    for (int pass = 0; pass < 6; ++pass) {
+        hipLaunchKernelGGL(k_zb_hist, dim3(sb), dim3(ZB_HTHREADS), 0, s, keys, (long long)n, (const ZbState*)st, hist, pass);
+        hipLaunchKernelGGL(k_zb_scan<0>, dim3(1), dim3(1024), 0, s, st, cfg, hist, pass, 1.0, 0);
+    }
+    if (loss == RBL_LOSS_BCE) {
+        hipLaunchKernelGGL(k_zb_risk<0>, dim3(hb), dim3(ZB_THREADS), 0, s, keys, (long long)n, (const ZbState*)st, cfg, partials);
+        hipLaunchKernelGGL(k_zb_risk_finish<0>, dim3(1), dim3(256), 0, s, (const ZbState*)st, cfg, (const double*)partials, hb, out_dev);
+    } else {
+        hipLaunchKernelGGL(k_zb_risk<1>, dim3(hb), dim3(ZB_THREADS), 0, s, keys, (long long)n, (const ZbState*)st, cfg, partials);
+        hipLaunchKernelGGL(k_zb_risk_finish<1>, dim3(1), dim3(256), 0, s, (const ZbState*)st, cfg, (const double*)partials, hb, out_dev);
+    }
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }
