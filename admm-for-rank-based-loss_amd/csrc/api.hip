@@ -106,7 +106,7 @@ struct rbl_solver {
     // z-step without a sort for piecewise-constant rank weights (zband.hip); `used`: this iteration's z came from it
     // and its status word has not been looked at yet
     struct {
-        bool checked = false, enabled = false, used = false, c_ready = false;
+        bool checked = false, enabled = false, used = false, c_ready = false, q_done = false;
         ZbConfig cfg;
         ZbState* st = nullptr;
         u32* hist = nullptr;
@@ -674,6 +674,46 @@ fail:
         RBL_HIP(hipSetDevice((h)->cfg.device));        \
     } while (0)
 
+// The sort-free z-step (zband.hip) reports through a pinned word whether it could certify its result.  Whoever is about
+// to look at z (or at the q formed from it) before rbl_phase_w has done so settles it here: wait for the word; not
+// certified -> the z-step (and q, if rbl_phase_q has run) is redone with the sort + merge-tree PAV, and the fast path
+// pauses for 2, 4, ... 64 iterations (the first iterations pool most of the rows in one block; that passes).
+// *redone (optional): tells rbl_phase_w that its w-step has to be repeated.
+int zb_resolve(rbl_solver* h, bool* redone = nullptr) {
+    if (redone) *redone = false;
+    if (!h->zb.used) return RBL_OK;
+    h->zb.used = false;
+    volatile int* pin = h->zb.pin;
+    if (pin[0] != h->zb.seq) rbl_spin_wait(pin, 0, h->stream);
+    if (pin[0] != h->zb.seq) {
+        rbl_set_error("banded z-step: its status word was never written");
+        (void)hipGetLastError();
+        return RBL_ERR_HIP;
+    }
+    if (pin[1] == ZB_OK) {
+        h->zb.backoff = 0;
+        return RBL_OK;
+    }
+    h->zb.backoff = h->zb.backoff < 2 ? 2 : (h->zb.backoff >= 32 ? 64 : 2 * h->zb.backoff);
+    h->zb.skip_until = h->iter + 1 + h->zb.backoff;
+    h->zb.mode = 2;
+    static const bool zb_debug = [] {
+        const char* e = getenv("RBL_ZBAND_DEBUG");
+        return e && e[0] == '1';
+    }();
+    if (zb_debug) fprintf(stderr, "[rbl] iteration %lld: banded z-step not certified (status %d), redone with the sort\n",
+                          (long long)h->iter, (int)pin[1]);
+    const bool q_done = h->zb.q_done;
+    h->zb.c_ready = h->zb.q_done = false;
+    RBL_TRY(z_step_sorted(h, h->m, h->step_rho));
+    if (q_done) {
+        RBL_TRY(launch_make_c(h->n, h->z, h->lam, h->step_rho, h->c, h->stream));
+        RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream));
+    }
+    if (redone) *redone = true;
+    return RBL_OK;
+}
+
 // w_{k+1} was computed ahead of time (rbl_phase_finish); anything that looks at or replaces the
 // state between two iterations must see w_k: put it back (the w-step is simply redone later).
 int cancel_spec(rbl_solver* h) {
@@ -689,6 +729,7 @@ int cancel_spec(rbl_solver* h) {
 #define RBL_ENTER(h)              \
     do {                          \
         RBL_ENTER_ITER(h);        \
+        RBL_TRY(zb_resolve(h));   \
         RBL_TRY(cancel_spec(h));  \
     } while (0)
 
@@ -1067,6 +1108,7 @@ int rbl_phase_z(rbl_solver* h, const void* m_all_dev) {
             RBL_TRY(launch_zband(h->cfg.loss, h->zb.cfg, h->n, rho, h->sw.keys[0], h->m, h->z, h->lam, h->c, h->zb.st, h->zb.hist,
                                  h->zb.part, h->zb.pin, h->zb.seq, h->pw.counters, h->stream));
             h->zb.used = true;
+            h->zb.q_done = false;
             h->zb.c_ready = true;   // the element-wise pass wrote c = z + lambda/rho as well
             h->zb.mode = 1;
         } else {
@@ -1104,6 +1146,7 @@ int rbl_phase_z_external(rbl_solver* h, const double* z) {
 
 int rbl_phase_w_external(rbl_solver* h, const double* w) {
     RBL_ENTER_ITER(h);
+    RBL_TRY(zb_resolve(h));   // the caller's w was formed from a z (and q) it could only read through the resolving entries
     if (!w) {
         rbl_set_error("phase_w_external: w is NULL");
         return RBL_ERR_INVALID;
@@ -1138,6 +1181,7 @@ int rbl_phase_q(rbl_solver* h) {
         // the per-row division on the sweep's critical path costs 0.9 ms, the streaming pass 30 us.)
         if (h->sorted_path && !h->zb.c_ready) RBL_TRY(launch_make_c(h->n, h->z, h->lam, h->step_rho, h->c, h->stream));
         h->zb.c_ready = false;
+        h->zb.q_done = h->zb.used;   // q of an unsettled sort-free z-step (zb_resolve redoes it with the z-step)
         RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream,
                              prof_now(h) ? h->kev[3] : nullptr));
         if (prof_now(h)) h->kev_pending[1] = h->n > 0;
@@ -1219,37 +1263,12 @@ static int phase_w_body(rbl_solver* h) {
 int rbl_phase_w(rbl_solver* h) {
     RBL_ENTER_ITER(h);
     RBL_TRY(phase_w_body(h));
-    if (!h->zb.used) return RBL_OK;
-    // The sort-free z-step reports through a pinned word whether it could certify its result.  The w-step's own
-    // host wait is behind us, so the word (written milliseconds earlier in stream order) is there already.
-    h->zb.used = false;
-    volatile int* pin = h->zb.pin;
-    if (pin[0] != h->zb.seq) rbl_spin_wait(pin, 0, h->stream);
-    if (pin[0] != h->zb.seq) {
-        rbl_set_error("banded z-step: its status word was never written");
-        (void)hipGetLastError();
-        return RBL_ERR_HIP;
-    }
-    if (pin[1] == ZB_OK) {
-        h->zb.backoff = 0;
-        return RBL_OK;
-    }
-    // not certified (keys tied across a band edge, a block of another shape, an unresolved bracket): this iteration's
-    // z-step, q and w-step are redone with the sort + merge-tree PAV, and the fast path pauses for 2, 4, ... 64
-    // iterations (the first iterations pool most of the rows in one block; that passes).
-    h->zb.backoff = h->zb.backoff < 2 ? 2 : (h->zb.backoff >= 32 ? 64 : 2 * h->zb.backoff);
-    h->zb.skip_until = h->iter + 1 + h->zb.backoff;
-    h->zb.mode = 2;
-    static const bool zb_debug = [] {
-        const char* e = getenv("RBL_ZBAND_DEBUG");
-        return e && e[0] == '1';
-    }();
-    if (zb_debug) fprintf(stderr, "[rbl] iteration %lld: banded z-step not certified (status %d), redone with the sort\n",
-                          (long long)h->iter, (int)pin[1]);
+    // the w-step's own host wait is behind us, so the z-step's status word (written milliseconds earlier in stream
+    // order) is there already: no extra synchronisation.  Not certified: z and q were redone, the w-step follows
+    bool redone = false;
+    RBL_TRY(zb_resolve(h, &redone));
+    if (!redone) return RBL_OK;
     RBL_HIP(hipMemcpyAsync(h->w, h->w_prev, sizeof(double) * h->ld, hipMemcpyDeviceToDevice, h->stream));
-    RBL_TRY(z_step_sorted(h, h->m, h->step_rho));
-    RBL_TRY(launch_make_c(h->n, h->z, h->lam, h->step_rho, h->c, h->stream));
-    RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream));
     return phase_w_body(h);
 }
 

@@ -112,3 +112,37 @@ def test_banded_z_step_is_reproducible(R, monkeypatch):
         assert modes.count(1) >= 10, modes
         outs.append(s.get_state())
     assert np.array_equal(outs[0]["w"], outs[1]["w"]) and np.array_equal(outs[0]["z"], outs[1]["z"])
+
+
+@pytest.mark.parametrize("loss,args,expect", [("hinge", [0.2, 0.8], 1), ("binary_cross_entropy", [0.45, 0.55], 2)],
+                         ids=["certified", "redone_with_the_sort"])
+def test_reading_z_mid_iteration_settles_the_fast_path(R, monkeypatch, loss, args, expect):
+    """hook contract (algorithms.py:88-116 mirrored in src/optim/algorithms.py): an overridden w_subproblem that looks at
+    z before the library's w-step must see a certified z - the read settles the sort-free z-step, and where that was
+    not certified the sort path's z is what it gets.  Same trajectory, bit for bit, as the run that never looks."""
+    from oracle import problems
+    from admm_for_rank_based_loss_amd.src.optim.algorithms import Optimizer
+    monkeypatch.setenv("RBL_ZBAND_MIN_N", "16")
+    X, y = problems.make_problem(3000, 16, seed=5)
+    kw = dict(weight_function="aorr", loss=loss, l2_reg=1e-4, args=args, max_iter=14, tol=0.0, storage="f64")
+
+    class Peek(R.ADMMmethod):
+        peeked = None
+
+        def w_subproblem(self):
+            self.peeked.append(self._s.get_state(want_lam=False)["z"].copy())
+            return super().w_subproblem()
+
+    runs = []
+    for cls in (R.ADMMmethod, Peek):
+        s = cls(X, y, **kw)
+        s.peeked = []
+        modes = []
+        for i in range(kw["max_iter"]):
+            Optimizer.main_loop(s, i, 0.0, False)          # one iteration (ADMMmethod.main_loop is the loop over them)
+            modes.append(s._last.zband)
+        runs.append((s._s.get_state(), modes, s.peeked))
+    (a, ma, _), (b, mb, zs) = runs
+    assert ma == mb and expect in mb, (ma, mb)               # the branch this case is about was exercised
+    assert np.array_equal(a["w"], b["w"]) and np.array_equal(a["z"], b["z"]) and np.array_equal(a["lam"], b["lam"])
+    assert np.array_equal(zs[-1], b["z"])                   # what the hook saw is the z of that iteration
