@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RBL_VERSION 101
+#define RBL_VERSION 102
 
 /* status codes */
 enum {
