@@ -7,7 +7,9 @@ Against the UNROUNDED matrix (`RAW=1` in the environment) fp32 storage is a pert
 measured 2e-4 on the convex families over 12 iterations and up to 7e-4 (EHRM) / 5e-2 (AoRR) on the
 non-convex ones, whose trajectories amplify the 6e-8 relative perturbation of D.
 Round 1: 660 fp64 trials (seeds 1-5 and 7, rows up to 80 000), worst relative deviation 8e-14.  Round 2 (seed 21,
-150 trials with sADMM runs (*), rank-weighted widths up to 1030 and 40 % fp32 storage): no mismatch."""
+150 trials with sADMM runs (*), rank-weighted widths up to 1030 and 40 % fp32 storage): no mismatch; seed 31, 150
+trials with RBL_ZBAND_MIN_N=16 in the environment (the 54 superquantile / aorr draws take the sort-free z-step and
+objective of csrc/zband.hip): no mismatch."""
 import os
 import sys
 import time
