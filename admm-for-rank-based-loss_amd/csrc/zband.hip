@@ -1,4 +1,5 @@
-// zband.hip - the z-step for PIECEWISE-CONSTANT rank weights without a sort (superquantile, aorr, aorr_dc).
+// zband.hip - the z-step (and the logged objective) for PIECEWISE-CONSTANT rank weights without a sort
+// (superquantile, aorr; aorr_dc's two single-rank bands in a row stay on the sort).
 //
 // Reference path: src/optim/algorithms.py:96-104 (z_subproblem: argsort m, PAV_solver, unsort) with
 // src/util/pav.py:84-161.  With weights that are constant on a few rank bands
@@ -13,14 +14,16 @@
 //   1. the keys at a handful of ranks (the last / first rank of each band): an MSD radix SELECT, 11 bits per pass
 //      over the 64-bit keys (integer histograms: exact and order-independent);
 //   2. the root of psi: passes that evaluate the block sums for 16 candidate values at once (thresholds in m-space,
-//      u_i > x  <=>  m_i > x + (s/rho) l'(x)), every pass shrinking the bracket 15x, until no element's membership
-//      changes inside the bracket - then the block is known exactly and its value is pav.py's own formula;
+//      u_i > x  <=>  m_i > x + (s/rho) l'(x)); the first pass packs its candidates around a prediction from the last
+//      three block values, the others shrink the bracket 15x each; once at most 2048 elements are undecided they are
+//      gathered and one workgroup settles the block exactly (its value is pav.py's own formula);
 //   3. one element-wise pass.
 // All sums are accumulated per thread in a fixed element order and reduced in a fixed order: bit-reproducible.
 // Whatever the fast path cannot certify (keys tied across a band edge, a block that swallows a whole band or stays
 // on one side of a single-rank band, an unresolved bracket) is REPORTED through a pinned status word; the caller
-// (api.hip) then runs the sort + merge-tree PAV for that iteration.  6M rows, superquantile: ~0.3 ms instead of
-// ~1.1 ms for sort + PAV + unsort.
+// (api.hip: zb_resolve) then runs the sort + merge-tree PAV for that iteration.  6M rows, superquantile: ~0.35 ms
+// instead of ~1.1 ms for sort + PAV + unsort.  The same select gives the logged objective sum_k sigma_k loss(v_(k))
+// without sorting v (k_zb_risk).  CPU restatement of the structure and of the certification rules: oracle/zband.py.
 #include "rbl_internal.h"
 #include "device_math.h"
 
@@ -126,10 +129,6 @@ __global__ __launch_bounds__(ZB_HTHREADS) void k_zb_hist(const u64* __restrict__
     }
 }
 
-template <int LOSS>
-__device__ inline double zb_dl(double x) {   // l'(x) (hinge: right derivative)
-    return LOSS == 0 ? rbl::sigmoid1(x) : (x >= -1.0 ? 1.0 : 0.0);
-}
 // u_i > x  <=>  m_i > zb_theta_gt(x);   u_i < x  <=>  m_i < zb_theta_lt(x)     (u_i = prox_{s l / rho}(m_i))
 template <int LOSS>
 __device__ inline double zb_theta_gt(double s_over_rho, double x) {
