@@ -146,3 +146,29 @@ def test_reading_z_mid_iteration_settles_the_fast_path(R, monkeypatch, loss, arg
     assert ma == mb and expect in mb, (ma, mb)               # the branch this case is about was exercised
     assert np.array_equal(a["w"], b["w"]) and np.array_equal(a["z"], b["z"]) and np.array_equal(a["lam"], b["lam"])
     assert np.array_equal(zs[-1], b["z"])                   # what the hook saw is the z of that iteration
+
+
+def test_banded_z_step_against_the_reference_goldens(R, monkeypatch):
+    """g4_zstep.npz holds z_subproblem() outputs of the REAL reference; its superquantile / aorr cases through the
+    sort-free z-step (forced onto 500 rows, iteration counter past 0 so that the fast path is taken)."""
+    import json
+    from conftest import load_golden
+    monkeypatch.setenv("RBL_ZBAND_MIN_N", "16")
+    g = load_golden("g4_zstep.npz")
+    seen = 0
+    for k in range(int(g["ncases"])):
+        cfg = json.loads(str(g[f"c{k}_name"]))
+        if cfg["weight_function"] not in ("superquantile", "aorr"):
+            continue
+        X, y, w, lam, zref = g[f"c{k}_X"], g[f"c{k}_y"], g[f"c{k}_w"], g[f"c{k}_lam"], g[f"c{k}_z"]
+        kw = {a: cfg[a] for a in ("l2_reg", "l1_reg", "B", "args") if a in cfg}
+        s = R.ADMMmethod(X, y, cfg["weight_function"], cfg["loss"], storage="f64", **kw)
+        s.w, s.lagrangian, s.rho = w, lam, cfg["rho"]
+        s._s.set_state(iter=3)
+        s._z_subproblem()
+        z = s.z                                  # reading z settles the fast path (sort path if it was not certified)
+        st = s._s.step(False)                    # (the step's report tells which path this handle is on)
+        assert np.max(np.abs(z - zref)) <= (1e-7 if cfg["loss"] == "binary_cross_entropy" else 1e-2), cfg
+        assert st.zband in (0, 1, 2)
+        seen += 1
+    assert seen >= 2

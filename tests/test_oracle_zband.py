@@ -66,3 +66,24 @@ def test_bands_and_clusters():
     s, v = zband.bands_of(weights.aorr(1000, 0.2, 0.8))
     cl = zband.clusters_of(s, v)
     assert cl[0][2] is True and cl[-1][2] is False and cl[-1][1] == len(v) - 1      # the upper edge cannot pool
+
+
+def test_banded_z_step_against_the_reference_goldens():
+    """g4_zstep.npz: z = z_subproblem() of the REAL reference (tests/golden/make_goldens.py) - the banded families in it"""
+    import json
+    from conftest import load_golden
+    g = load_golden("g4_zstep.npz")
+    seen = 0
+    for k in range(int(g["ncases"])):
+        cfg = json.loads(str(g[f"c{k}_name"]))
+        if cfg["weight_function"] not in ("superquantile", "aorr"):
+            continue
+        X, y, w, lam, zref = g[f"c{k}_X"], g[f"c{k}_y"], g[f"c{k}_w"], g[f"c{k}_lam"], g[f"c{k}_z"]
+        rho = cfg["rho"]
+        m = ((-y * X) @ w - lam / rho).reshape(-1)
+        sigma, _ = weights.get_weights(cfg["weight_function"], X.shape[0], cfg["args"])
+        z, status = zband.z_step(cfg["loss"], sigma, rho, m)
+        assert status == zband.OK, cfg
+        assert np.max(np.abs(z - zref.reshape(-1))) <= (1e-8 if cfg["loss"] == "binary_cross_entropy" else 1e-2), cfg
+        seen += 1
+    assert seen >= 2
