@@ -346,7 +346,13 @@ __global__ __launch_bounds__(1024) void k_colreduce(const double* __restrict__ s
     }
 }
 
-constexpr int GEMVT_BLOCKS_PER_CU = 4;
+#ifndef RBL_GEMVT_BPC
+#define RBL_GEMVT_BPC 4
+#endif
+#ifndef RBL_GEMVT_U
+#define RBL_GEMVT_U 8   // rows in flight per thread in the one-packet-per-thread instance (d <= 1024 fp32)
+#endif
+constexpr int GEMVT_BLOCKS_PER_CU = RBL_GEMVT_BPC;
 
 template <typename T, int TPR, bool SQ>
 int gemvt_dispatch(const T* D, long long n, long long ld, const double* c, double* slab, double* slab2,
@@ -364,7 +370,7 @@ int gemvt_dispatch(const T* D, long long n, long long ld, const double* c, doubl
         hipLaunchKernelGGL((k_gemvt<T, TPR, 1, 8, SQ>), grid, dim3(256), 0, s, D, n, ld, c, slab, slab2);
     } else {
         if (pj == 1)
-            hipLaunchKernelGGL((k_gemvt<T, TPR, 1, 8, SQ>), grid, dim3(256), 0, s, D, n, ld, c, slab, slab2);
+            hipLaunchKernelGGL((k_gemvt<T, TPR, 1, RBL_GEMVT_U, SQ>), grid, dim3(256), 0, s, D, n, ld, c, slab, slab2);
         else if (pj == 2)
             hipLaunchKernelGGL((k_gemvt<T, TPR, 2, 4, SQ>), grid, dim3(256), 0, s, D, n, ld, c, slab, slab2);
         else if (pj <= 4)
