@@ -438,7 +438,7 @@ int zb_setup(rbl_solver* h) {
         if (c.nclusters == ZB_MAX_CLUSTERS) return RBL_OK;
         bool up = false;
         for (int q = L; q < j; ++q) up = up || c.sigma[q + 1] > c.sigma[q];
-        if (j - L > 2) return RBL_OK;   // two or more single-rank bands in a row (aorr_dc): left to the sort
+        if (j - L > 3) return RBL_OK;   // more than two single-rank bands in a row: left to the sort
         c.cl_L[c.nclusters] = L;
         c.cl_R[c.nclusters] = j;
         c.cl_root[c.nclusters] = up ? 1 : 0;

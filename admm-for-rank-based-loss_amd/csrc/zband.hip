@@ -1,5 +1,5 @@
 // zband.hip - the z-step (and the logged objective) for PIECEWISE-CONSTANT rank weights without a sort
-// (superquantile, aorr; aorr_dc's two single-rank bands in a row stay on the sort).
+// (superquantile, aorr, aorr_dc: up to two single-rank bands between two bands of several ranks).
 //
 // Reference path: src/optim/algorithms.py:96-104 (z_subproblem: argsort m, PAV_solver, unsort) with
 // src/util/pav.py:84-161.  With weights that are constant on a few rank bands
@@ -325,11 +325,16 @@ __global__ __launch_bounds__(1024) void k_zb_scan(ZbState* __restrict__ st, ZbCo
 }
 
 // What a certified block may look like.  A whole band may be pooled only where nothing lies beyond it (the first / the
-// last band).  With elements of both neighbouring bands the single-rank bands are inside; a block that stays on one
-// side is certified only around ONE single-rank band e: {top of L, e} needs u_e <= x, {e, bottom of R} needs u_e >= x
-// (pav.py pools e with a neighbouring block exactly then).  cT / cB: elements of L / R in the block.
+// last band).  The root was computed for "top of L + every single-rank band + bottom of R"; that IS the pooled block
+// of pav.py iff every prefix of it pools to a value >= x (else the prefix would stay a block of its own):
+//   no single-rank band:   both sides must be present (one band alone never pools);
+//   one (e):               both sides present - always; only the top: u_e <= x; only the bottom: u_e >= x;
+//   two (e1, e2; aorr_dc): both sides present - the prefix "top of L + e1" must pool to >= x (equivalently
+//                          "e2 + bottom of R" to <= x); only the top: u_e2 <= x; only the bottom or neither: u_e1 >= x.
+// cT, mT / cB, mB: count and sum of m of the elements of L / R in the block.
 template <int LOSS>
-__device__ void zb_accept(ZbState* st, const ZbConfig& cfg, int k, double rho, double x, double cT, double cB) {
+__device__ void zb_accept(ZbState* st, const ZbConfig& cfg, int k, double rho, double x, double cT, double mT, double cB,
+                          double mB) {
     const int L = cfg.cl_L[k], R = cfg.cl_R[k];
     const double sizeL = (double)(cfg.start[L + 1] - cfg.start[L]), sizeR = (double)(cfg.start[R + 1] - cfg.start[R]);
     if (!(cT < sizeL || L == 0)) {
@@ -340,16 +345,30 @@ __device__ void zb_accept(ZbState* st, const ZbConfig& cfg, int k, double rho, d
         st->status = ZB_SWALLOW_R;
         return;
     }
-    if (!(cT > 0.0 && cB > 0.0)) {
-        bool ok = false;
-        if (R - L == 2) {
-            const double ue = rbl::prox<LOSS>(cfg.sigma[L + 1], rho, rbl::unflip_key(st->key[cfg.first_t[L + 1]]));
-            ok = cT > 0.0 ? ue <= x : (cB > 0.0 ? ue >= x : true);
+    const int nt = R - L - 1;
+    bool ok;
+    if (nt == 0) {
+        ok = cT > 0.0 && cB > 0.0;
+    } else {
+        const double s1 = cfg.sigma[L + 1], m1 = rbl::unflip_key(st->key[cfg.first_t[L + 1]]);
+        const double s2 = cfg.sigma[R - 1], m2 = rbl::unflip_key(st->key[cfg.first_t[R - 1]]);   // (nt == 1: the same band)
+        const double u1 = rbl::prox<LOSS>(s1, rho, m1), u2 = rbl::prox<LOSS>(s2, rho, m2);
+        if (cT > 0.0 && cB > 0.0) {
+            ok = true;
+            if (nt == 2) {
+                const double xl = zb_block_value<LOSS>(cfg.sigma[L] * cT + s1, mT + m1, cT + 1.0, rho);
+                const double xr = zb_block_value<LOSS>(s2 + cfg.sigma[R] * cB, m2 + mB, 1.0 + cB, rho);
+                ok = xl >= x && xr <= x;
+            }
+        } else if (cT > 0.0) {
+            ok = u2 <= x;
+        } else {
+            ok = u1 >= x;
         }
-        if (!ok) {
-            st->status = ZB_ONESIDED;
-            return;
-        }
+    }
+    if (!ok) {
+        st->status = ZB_ONESIDED;
+        return;
     }
     st->x[k] = x;
     st->xh[k][2] = st->xh[k][1];
@@ -532,7 +551,7 @@ __global__ __launch_bounds__(1024) void k_zb_refine(ZbState* __restrict__ st, Zb
             c1 = c;
             break;
         }
-    double x = 0.0, cT = 0.0, cB = 0.0;
+    double x = 0.0, cT = 0.0, cB = 0.0, mT = 0.0, mB = 0.0;
     bool found = false;
     if (c1 < 0 || (c1 == 0 && psi[0] > 0.0)) {
         st->status = ZB_BRACKET;   // the root is not inside the bracket: cannot happen for a consistent chain
@@ -545,12 +564,16 @@ __global__ __launch_bounds__(1024) void k_zb_refine(ZbState* __restrict__ st, Zb
         // elements whose prox sits on the plateau are part of the block (top part as left of -1, bottom part as right of it)
         x = -1.0;
         cT = NT[c1 - 1];
+        mT = MT[c1 - 1];
         cB = NB[c1];
+        mB = MB[c1];
         found = true;
     } else if (psi[c1] == 0.0) {
         x = st->cand[k][c1];
         cT = NT[c1];
+        mT = MT[c1];
         cB = NB[c1];
+        mB = MB[c1];
         found = true;
     } else {
         const int c0 = c1 - 1;
@@ -558,9 +581,11 @@ __global__ __launch_bounds__(1024) void k_zb_refine(ZbState* __restrict__ st, Zb
         if (undecided == 0.0) {
             // no element changes sides inside (x_c0, x_c1): top part as at x_c1, bottom part as at x_c0
             cT = NT[c1];
+            mT = MT[c1];
             cB = NB[c0];
+            mB = MB[c0];
             const double cnt = cT + nt + cB;
-            x = zb_block_value<LOSS>(sL * cT + At + sR * cB, MT[c1] + Mt + MB[c0], cnt, rho);
+            x = zb_block_value<LOSS>(sL * cT + At + sR * cB, mT + Mt + mB, cnt, rho);
             if (!(x >= st->cand[k][c0] && x <= st->cand[k][c1])) {
                 st->status = ZB_BRACKET;
                 return;
@@ -586,7 +611,7 @@ __global__ __launch_bounds__(1024) void k_zb_refine(ZbState* __restrict__ st, Zb
             }
         }
     }
-    if (found) zb_accept<LOSS>(st, cfg, k, rho, x, cT, cB);
+    if (found) zb_accept<LOSS>(st, cfg, k, rho, x, cT, mT, cB, mB);
 }
 
 // ------------------------------------------------------------------------------------------ gather + finish
@@ -772,7 +797,7 @@ __global__ __launch_bounds__(1024) void k_zb_finish(ZbState* __restrict__ st, Zb
         st->status = ZB_BRACKET;
         return;
     }
-    zb_accept<LOSS>(st, cfg, k, rho, x, cT, cB);
+    zb_accept<LOSS>(st, cfg, k, rho, x, cT, mT, cB, mB);
 }
 
 // ------------------------------------------------------------------------------------------ objective

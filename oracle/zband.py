@@ -41,8 +41,8 @@ def clusters_of(starts, values):
     for j in range(1, nb):
         if size[j] == 1:
             continue
-        if j - L > 2:
-            return None                    # two single-rank bands in a row (aorr_dc): left to the sort
+        if j - L > 3:
+            return None                    # more than two single-rank bands in a row: left to the sort
         out.append((L, j, bool(np.any(np.diff(values[L:j + 1]) > 0))))
         L = j
     return out
@@ -121,13 +121,26 @@ def z_step(loss, sigma, rho, m):
             return None, SWALLOW_L
         if not (cB < bot_u.size or R == nb - 1):
             return None, SWALLOW_R
-        if not (cT > 0 and cB > 0):
-            ok = False
-            if R - L == 2:
-                ue = u[band == L + 1][0]
-                ok = ue <= x if cT > 0 else (ue >= x if cB > 0 else True)
-            if not ok:
-                return None, ONESIDED
+        # the root was computed for "top of L + every single-rank band + bottom of R"; it is pav.py's block iff every
+        # prefix of it pools to a value >= x (csrc/zband.hip: zb_accept)
+        ntiny = R - L - 1
+        if ntiny == 0:
+            ok = cT > 0 and cB > 0
+        else:
+            s1, m1, u1 = values[L + 1], m[band == L + 1][0], u[band == L + 1][0]
+            s2, m2, u2 = values[R - 1], m[band == R - 1][0], u[band == R - 1][0]
+            if cT > 0 and cB > 0:
+                ok = True
+                if ntiny == 2:
+                    xl = _pav.block_value(loss, values[L] * cT + s1, mT + m1, cT + 1.0, rho)
+                    xr = _pav.block_value(loss, s2 + values[R] * cB, m2 + mB, 1.0 + cB, rho)
+                    ok = xl >= x and xr <= x
+            elif cT > 0:
+                ok = u2 <= x
+            else:
+                ok = u1 >= x
+        if not ok:
+            return None, ONESIDED
         hi[L] = x
         lo[R] = x
         for j in range(L + 1, R):

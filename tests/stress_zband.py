@@ -17,8 +17,12 @@ for trial in range(trials):
     d = int(rng.choice([3, 8, 24, 65]))
     loss = str(rng.choice(["binary_cross_entropy", "hinge"]))
     wstep = int(rng.choice([1, 2]))
-    if rng.random() < 0.5:
+    pick = rng.random()
+    if pick < 0.4:
         wf, args = "superquantile", [float(rng.choice([0.5, 0.9, 0.1, round(float(rng.uniform(0.05, 0.95)), 3)]))]
+    elif pick < 0.6:
+        mm = int(rng.uniform(0.02, 0.5) * n)
+        wf, args = "aorr_dc", [int(min(n - 4, mm + max(3, rng.uniform(0.05, 0.45) * n))), mm]
     else:
         lo = float(rng.uniform(0.02, 0.6))
         wf, args = "aorr", [round(lo, 3), round(float(rng.uniform(lo + 0.1, 0.99)), 3)]

@@ -16,7 +16,7 @@ def _exact(loss, sigma, rho, m):
 
 
 CASES = [("superquantile", [0.5]), ("superquantile", [0.37]), ("superquantile", [0.9]), ("aorr", [0.2, 0.8]), ("aorr", [0.13, 0.71]),
-         ("aorr", [0.45, 0.55])]
+         ("aorr", [0.45, 0.55]), ("aorr_dc", [0.7, 0.1]), ("aorr_dc", [0.35, 0.3])]   # aorr_dc: (k, m) as fractions of n here
 
 
 @pytest.mark.parametrize("loss", ["binary_cross_entropy", "hinge"])
@@ -26,7 +26,7 @@ def test_banded_z_step_equals_exact_pav(loss, wf, args):
     seen = {zband.OK: 0}
     for trial in range(40):
         n = int(rng.choice([50, 333, 2000, 9001]))
-        sigma, _ = weights.get_weights(wf, n, args)
+        sigma, _ = weights.get_weights(wf, n, [int(args[0] * n), int(args[1] * n)] if wf == "aorr_dc" else args)
         # the regimes of an ADMM run: the shift sigma/rho of the prox from a few spreads of m ("one block holds most
         # rows") down to a thousandth of it ("a handful of rows pool")
         spread = float(10.0 ** rng.uniform(-3, 1))
@@ -48,8 +48,10 @@ def test_banded_z_step_reports_what_it_cannot_certify():
     sigma, _ = weights.get_weights("superquantile", n, [0.5])
     z, status = zband.z_step("binary_cross_entropy", sigma, 1e-5, np.zeros(n))        # iteration 0: every m equal
     assert z is None and status == zband.TIE
-    sigma_dc, _ = weights.get_weights("aorr_dc", n, [300, 40])                          # two single-rank bands in a row
-    assert zband.z_step("binary_cross_entropy", sigma_dc, 1e-3, np.random.default_rng(0).normal(size=n))[1] == zband.UNSUPPORTED
+    three = np.zeros(n)                                                                  # three single-rank bands in a row
+    three[400:500] = 1e-3
+    three[501], three[503] = 5e-4, 7e-4
+    assert zband.z_step("binary_cross_entropy", three, 1e-3, np.random.default_rng(0).normal(size=n))[1] == zband.UNSUPPORTED
     smooth, _ = weights.get_weights("extremile", n, [2.0])                              # every rank its own weight
     assert zband.z_step("binary_cross_entropy", smooth, 1e-3, np.random.default_rng(0).normal(size=n))[1] == zband.UNSUPPORTED
     # AoRR with a narrow middle band and a tiny rho: the block at the lower edge swallows the whole middle band
