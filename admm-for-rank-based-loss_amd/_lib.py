@@ -19,6 +19,7 @@ STORAGE = {"f32": 0, "float32": 0, "f64": 1, "float64": 1}
 BUF_M, BUF_Q, BUF_RED, BUF_G, BUF_V, BUF_Z, BUF_LAM, BUF_W, BUF_COLSTATS = range(9)
 (BUF_ZD_SKEYS, BUF_ZD_SIDS, BUF_ZD_RKEYS, BUF_ZD_RIDS, BUF_ZD_SMALL, BUF_ZD_BIDS, BUF_ZD_BU, BUF_ZD_ZIDS,
  BUF_ZD_ZU, BUF_ZD_COUNTS) = range(16, 26)
+BUF_ZB_HIST, BUF_ZB_TOT, BUF_ZB_PACK = 26, 27, 28
 KERNEL_GEMV, KERNEL_GEMVT, KERNEL_SWEEP_ERM = 0, 1, 2
 
 
@@ -102,6 +103,14 @@ SIGNATURES = {
     "rbl_zd_seam_fill": (C.c_int, [_P, C.c_void_p]),
     "rbl_zd_return_partition": (C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
     "rbl_zd_scatter": (C.c_int, [_P, C.c_int64]),
+    "rbl_zbd_begin": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rbl_zbd_hist": (C.c_int, [_P, C.c_int]),
+    "rbl_zbd_scan": (C.c_int, [_P, C.c_int]),
+    "rbl_zbd_eval": (C.c_int, [_P, C.c_int]),
+    "rbl_zbd_decide": (C.c_int, [_P, C.c_int, C.c_int]),
+    "rbl_zbd_gather": (C.c_int, [_P, C.c_int]),
+    "rbl_zbd_finish": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int]),
+    "rbl_zbd_apply": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "rbl_phase_q": (C.c_int, [_P]),
     "rbl_phase_w": (C.c_int, [_P]),
     "rbl_phase_dual": (C.c_int, [_P, C.c_int]),

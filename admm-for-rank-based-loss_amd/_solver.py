@@ -314,6 +314,36 @@ class Solver:
     def zd_scatter(self, n_back):
         _lib.check(self.lib.rbl_zd_scatter(self._h, int(n_back)))
 
+    # sort-free distributed z-step for banded rank weights (include/rbl.h: rbl_zbd_*)
+    def zbd_begin(self):
+        """-> (applicable, [clusters that can pool])"""
+        a, mask = C.c_int(0), C.c_int(0)
+        _lib.check(self.lib.rbl_zbd_begin(self._h, C.byref(a), C.byref(mask)))
+        return bool(a.value), [k for k in range(8) if mask.value >> k & 1]
+
+    def zbd_hist(self, p):
+        _lib.check(self.lib.rbl_zbd_hist(self._h, int(p)))
+
+    def zbd_scan(self, p):
+        _lib.check(self.lib.rbl_zbd_scan(self._h, int(p)))
+
+    def zbd_eval(self, k):
+        _lib.check(self.lib.rbl_zbd_eval(self._h, int(k)))
+
+    def zbd_decide(self, k, last):
+        _lib.check(self.lib.rbl_zbd_decide(self._h, int(k), int(bool(last))))
+
+    def zbd_gather(self, k):
+        _lib.check(self.lib.rbl_zbd_gather(self._h, int(k)))
+
+    def zbd_finish(self, k, packs_all_ptr, world):
+        _lib.check(self.lib.rbl_zbd_finish(self._h, int(k), C.c_void_p(int(packs_all_ptr)), int(world)))
+
+    def zbd_apply(self):
+        st = C.c_int(0)
+        _lib.check(self.lib.rbl_zbd_apply(self._h, C.byref(st)))
+        return st.value
+
     def pending_reduce(self):
         m = C.c_int(0)
         _lib.check(self.lib.rbl_pending_reduce(self._h, C.byref(m)))

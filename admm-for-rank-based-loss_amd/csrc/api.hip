@@ -111,6 +111,8 @@ struct rbl_solver {
         ZbState* st = nullptr;
         u32* hist = nullptr;
         double* part = nullptr;
+        double* tot = nullptr;     // multi-GPU: the sums of one root pass (all-reduced by the driver)
+        double* pack = nullptr;    // multi-GPU: [count | undecided elements] of this rank (all-gathered by the driver)
         int* pin = nullptr;    // pinned: [0] sequence number (written last), [1] status
         int seq = 0, mode = 0;
         int64_t backoff = 0, skip_until = 0;   // after an uncertified z-step the fast path pauses for 2, 4, ... 64 iterations   // mode of the iteration in flight: 0 sort, 1 banded, 2 banded then redone with the sort
@@ -386,7 +388,9 @@ int zb_setup(rbl_solver* h) {
     if (off && off[0] == '1') return RBL_OK;
     const char* mn = getenv("RBL_ZBAND_MIN_N");
     const long long min_n = mn ? atoll(mn) : 65536;
-    if (!h->sorted_path || h->cfg.weight_function == RBL_W_EHRM || h->nt != h->n || h->n < min_n || h->n < 16) return RBL_OK;
+    // (the configuration speaks of GLOBAL ranks: a row-sharded handle builds the same one; its driver runs the steps with
+    // collectives in between - rbl_zbd_*)
+    if (!h->sorted_path || h->cfg.weight_function == RBL_W_EHRM || h->nt < min_n || h->nt < 16) return RBL_OK;
     constexpr int CAP = 16;
     long long* pos_dev = nullptr;
     int* cnt_dev = nullptr;
@@ -449,6 +453,8 @@ int zb_setup(rbl_solver* h) {
     RBL_HIP(hipMemset(h->zb.st, 0, sizeof(ZbState)));
     RBL_TRY(dev_alloc((unsigned char**)&h->zb.hist, zb_hist_bytes()));
     RBL_TRY(dev_alloc((unsigned char**)&h->zb.part, zb_partials_bytes()));
+    RBL_TRY(dev_alloc(&h->zb.tot, (size_t)(4 * ZB_C)));
+    RBL_TRY(dev_alloc(&h->zb.pack, (size_t)(ZB_GCAP + 1)));
     RBL_HIP(hipHostMalloc((void**)&h->zb.pin, 64, hipHostMallocDefault));
     h->zb.pin[0] = h->zb.pin[1] = 0;
     h->zb.enabled = true;
@@ -502,7 +508,7 @@ int rbl_destroy(rbl_solver* h) {
     dev_free(h->zd_locx_b); dev_free(h->zd_chunk_b); dev_free(h->zd_cph_b); dev_free(h->zd_cpl_b);
     free_sort(h->sw);
     free_pav(h->pw);
-    dev_free(h->zb.st); dev_free(h->zb.hist); dev_free(h->zb.part);
+    dev_free(h->zb.st); dev_free(h->zb.hist); dev_free(h->zb.part); dev_free(h->zb.tot); dev_free(h->zb.pack);
     if (h->zb.pin) (void)hipHostFree(h->zb.pin);
     dev_free(h->locx_a); dev_free(h->chunk_a); dev_free(h->cph_a); dev_free(h->cpl_a);
     dev_free(h->locx_b); dev_free(h->chunk_b); dev_free(h->cph_b); dev_free(h->cpl_b);
@@ -1102,7 +1108,7 @@ int rbl_phase_z(rbl_solver* h, const void* m_all_dev) {
         if (!h->zb.checked) RBL_TRY(zb_setup(h));
         h->zb.mode = 0;
         // iteration 0 starts from w = 0, lambda = 0: every m is equal, the keys tie across every band edge
-        if (h->zb.enabled && h->keys_ready && msrc == h->m && h->iter > 0 && h->iter >= h->zb.skip_until) {
+        if (h->zb.enabled && h->nt == h->n && h->keys_ready && msrc == h->m && h->iter > 0 && h->iter >= h->zb.skip_until) {
             h->zb.seq = (h->zb.seq & 0x3fffffff) + 1;
             h->zb.pin[0] = 0;
             RBL_TRY(launch_zband(h->cfg.loss, h->zb.cfg, h->n, rho, h->sw.keys[0], h->m, h->z, h->lam, h->c, h->zb.st, h->zb.hist,
@@ -1826,6 +1832,94 @@ int rbl_zd_scatter(rbl_solver* h, int64_t n_back) {
     return RBL_OK;
 }
 
+// ---- sort-free z-step for banded rank weights, sharded rows (zband.hip step by step; the driver sums / gathers in between)
+static int zbd_ready(rbl_solver* h) {
+    if (!h->zb.enabled || !h->keys_ready) {
+        rbl_set_error("rbl_zbd_*: call rbl_phase_m and rbl_zbd_begin (applicable) first");
+        return RBL_ERR_STATE;
+    }
+    return RBL_OK;
+}
+int rbl_zbd_begin(rbl_solver* h, int* applicable, int* root_clusters) {
+    RBL_ENTER_ITER(h);
+    if (applicable) *applicable = 0;
+    if (root_clusters) *root_clusters = 0;
+    if (!h->sorted_path) return RBL_OK;
+    if (!h->zb.checked) RBL_TRY(zb_setup(h));
+    h->zb.mode = 0;
+    // iteration 0 (every m equal) and the pause after an uncertified z-step: the caller takes the sort path
+    if (!(h->zb.enabled && h->keys_ready && h->iter > 0 && h->iter >= h->zb.skip_until)) return RBL_OK;
+    RBL_TRY(launch_zbd_init(h->zb.cfg, h->zb.st, h->zb.hist, h->stream));
+    if (applicable) *applicable = 1;
+    if (root_clusters) {
+        int mask = 0;
+        for (int k = 0; k < h->zb.cfg.nclusters; ++k) mask |= h->zb.cfg.cl_root[k] ? (1 << k) : 0;
+        *root_clusters = mask;   // bit k: cluster k can pool (rbl_zbd_eval / decide / gather / finish run for it)
+    }
+    return RBL_OK;
+}
+int rbl_zbd_hist(rbl_solver* h, int pass) {
+    RBL_ENTER_ITER(h);
+    RBL_TRY(zbd_ready(h));
+    return launch_zbd_hist(h->n, h->sw.keys[0], h->zb.st, h->zb.hist, pass, h->stream);
+}
+int rbl_zbd_scan(rbl_solver* h, int pass) {
+    RBL_ENTER_ITER(h);
+    RBL_TRY(zbd_ready(h));
+    return launch_zbd_scan(h->cfg.loss, h->zb.cfg, h->zb.st, h->zb.hist, pass, h->step_rho, h->stream);
+}
+int rbl_zbd_eval(rbl_solver* h, int k) {
+    RBL_ENTER_ITER(h);
+    RBL_TRY(zbd_ready(h));
+    return launch_zbd_eval(h->cfg.loss, h->zb.cfg, h->n, h->sw.keys[0], h->zb.st, k, h->step_rho, h->zb.part, h->zb.tot, h->stream);
+}
+int rbl_zbd_decide(rbl_solver* h, int k, int last) {
+    RBL_ENTER_ITER(h);
+    RBL_TRY(zbd_ready(h));
+    return launch_zbd_decide(h->cfg.loss, h->zb.cfg, h->zb.st, k, h->step_rho, h->zb.tot, last, h->stream);
+}
+int rbl_zbd_gather(rbl_solver* h, int k) {
+    RBL_ENTER_ITER(h);
+    RBL_TRY(zbd_ready(h));
+    return launch_zbd_gather(h->cfg.loss, h->zb.cfg, h->n, h->sw.keys[0], h->zb.st, k, h->step_rho, h->zb.part, h->zb.pack, h->stream);
+}
+int rbl_zbd_finish(rbl_solver* h, int k, const void* packs_all_dev, int world) {
+    RBL_ENTER_ITER(h);
+    RBL_TRY(zbd_ready(h));
+    if (!packs_all_dev || world < 1 || world > 64) return RBL_ERR_INVALID;
+    return launch_zbd_finish(h->cfg.loss, h->zb.cfg, h->zb.st, k, h->step_rho, h->zb.part, (const double*)packs_all_dev, world,
+                             h->stream);
+}
+int rbl_zbd_apply(rbl_solver* h, int* status) {
+    RBL_ENTER_ITER(h);
+    RBL_TRY(zbd_ready(h));
+    h->zb.seq = (h->zb.seq & 0x3fffffff) + 1;
+    h->zb.pin[0] = 0;
+    RBL_TRY(launch_zbd_apply(h->cfg.loss, h->zb.cfg, h->n, h->step_rho, h->m, h->z, h->lam, h->c, h->zb.st, h->zb.pin, h->zb.seq,
+                             h->pw.counters, h->stream));
+    // every rank holds the same state, so every rank reads the same verdict and takes the same branch afterwards
+    volatile int* pin = h->zb.pin;
+    rbl_spin_wait(pin, 0, h->stream);
+    if (pin[0] != h->zb.seq) {
+        rbl_set_error("banded z-step: its status word was never written");
+        (void)hipGetLastError();
+        return RBL_ERR_HIP;
+    }
+    if (status) *status = pin[1];
+    if (pin[1] == ZB_OK) {
+        h->zb.backoff = 0;
+        h->zb.c_ready = true;
+        h->zb.mode = 1;
+        h->keys_ready = false;
+        if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[1], h->stream));
+    } else {
+        h->zb.backoff = h->zb.backoff < 2 ? 2 : (h->zb.backoff >= 32 ? 64 : 2 * h->zb.backoff);
+        h->zb.skip_until = h->iter + 1 + h->zb.backoff;
+        h->zb.mode = 2;   // the caller runs the sort-based distributed z-step (rbl_zd_*) for this iteration
+    }
+    return RBL_OK;
+}
+
 int rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles) {
     RBL_ENTER(h);
     void* p = nullptr;
@@ -1851,6 +1945,9 @@ int rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles) {
         case RBL_BUF_ZD_ZIDS: RBL_TRY(zd_ensure(h)); p = h->zd_zids; cnt = h->n; break;
         case RBL_BUF_ZD_ZU: p = h->m; cnt = h->n; break;
         case RBL_BUF_ZD_COUNTS: RBL_TRY(zd_ensure(h)); p = h->zd_counts_dev; cnt = 64; break;
+        case RBL_BUF_ZB_HIST: p = h->zb.hist; cnt = h->zb.hist ? (int64_t)(zb_hist_bytes() / sizeof(u32)) : 0; break;
+        case RBL_BUF_ZB_TOT: p = h->zb.tot; cnt = h->zb.tot ? 4 * ZB_C : 0; break;
+        case RBL_BUF_ZB_PACK: p = h->zb.pack; cnt = h->zb.pack ? ZB_GCAP + 1 : 0; break;
         default: rbl_set_error("unknown buffer id %d", which); return RBL_ERR_INVALID;
     }
     if (dev_ptr) *dev_ptr = p;

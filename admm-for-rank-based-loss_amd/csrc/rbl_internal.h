@@ -303,3 +303,16 @@ int launch_zband(int loss, const ZbConfig& cfg, int64_t n, double rho, const u64
                  const double* lam, double* c, ZbState* st, u32* hist, double* partials, int* pin, int seq, u32* counters, hipStream_t s);
 int launch_zband_risk(int loss, const ZbConfig& cfg, int64_t n, const u64* keys, ZbState* st, u32* hist, double* partials,
                       double* out_dev, hipStream_t s);
+// the steps of launch_zband one by one (multi-GPU driver: collectives in between)
+int launch_zbd_init(const ZbConfig& cfg, ZbState* st, u32* hist, hipStream_t s);
+int launch_zbd_hist(int64_t n, const u64* keys, ZbState* st, u32* hist, int pass, hipStream_t s);
+int launch_zbd_scan(int loss, const ZbConfig& cfg, ZbState* st, u32* hist, int pass, double rho, hipStream_t s);
+int launch_zbd_eval(int loss, const ZbConfig& cfg, int64_t n, const u64* keys, ZbState* st, int k, double rho, double* partials,
+                    double* tot, hipStream_t s);
+int launch_zbd_decide(int loss, const ZbConfig& cfg, ZbState* st, int k, double rho, const double* tot, int last, hipStream_t s);
+int launch_zbd_gather(int loss, const ZbConfig& cfg, int64_t n, const u64* keys, ZbState* st, int k, double rho, double* partials,
+                      double* pack, hipStream_t s);
+int launch_zbd_finish(int loss, const ZbConfig& cfg, ZbState* st, int k, double rho, double* partials, const double* packs_all,
+                      int world, hipStream_t s);
+int launch_zbd_apply(int loss, const ZbConfig& cfg, int64_t n, double rho, const double* m, double* z, const double* lam, double* c,
+                     ZbState* st, int* pin, int seq, u32* counters, hipStream_t s);

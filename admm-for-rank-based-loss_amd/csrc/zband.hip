@@ -507,11 +507,21 @@ __global__ __launch_bounds__(ZB_THREADS) void k_zb_eval(const u64* __restrict__ 
 
 // one block: sums over the eval blocks, psi at the candidates, the next bracket or the block value
 template <int LOSS>
+// Across GPUs the two halves run as separate launches with an all-reduce in between: tot_out != NULL stops after the
+// local sums (written there, zeros when this cluster is settled), tot_in != NULL starts from the summed totals.
 __global__ __launch_bounds__(1024) void k_zb_refine(ZbState* __restrict__ st, ZbConfig cfg, int k, double rho,
-                                                     const double* __restrict__ partials, int nblocks, int last) {
-    if (st->status != ZB_OK || st->done[k] || st->und[k] <= (double)ZB_GCAP) return;
+                                                     const double* __restrict__ partials, int nblocks, int last,
+                                                     double* __restrict__ tot_out, const double* __restrict__ tot_in) {
+    const bool idle = st->status != ZB_OK || st->done[k] || st->und[k] <= (double)ZB_GCAP;
+    if (idle) {
+        if (tot_out && threadIdx.x < 4 * ZB_C) tot_out[threadIdx.x] = 0.0;
+        return;
+    }
     __shared__ double tot[4 * ZB_C];
-    {
+    if (tot_in) {
+        if (threadIdx.x < 4 * ZB_C) tot[threadIdx.x] = tot_in[threadIdx.x];
+        __syncthreads();
+    } else {
         // 16 threads per value (coalesced over the 64 values): thread (v, part) sums blocks part, part + 16, ... in
         // order, then the 16 partial sums in order
         const int v = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -527,6 +537,10 @@ __global__ __launch_bounds__(1024) void k_zb_refine(ZbState* __restrict__ st, Zb
             tot[v] = a;
         }
         __syncthreads();
+    }
+    if (tot_out) {
+        if (threadIdx.x < 4 * ZB_C) tot_out[threadIdx.x] = tot[threadIdx.x];
+        return;
     }
     if (threadIdx.x != 0) return;
     const int L = cfg.cl_L[k], R = cfg.cl_R[k];
@@ -800,6 +814,38 @@ __global__ __launch_bounds__(1024) void k_zb_finish(ZbState* __restrict__ st, Zb
     zb_accept<LOSS>(st, cfg, k, rho, x, cT, mT, cB, mB);
 }
 
+// ---- across GPUs: the undecided elements of all ranks
+// pack[0] = how many this rank gathered, pack[1 ...] = their m
+__global__ void k_zb_pack(const ZbState* __restrict__ st, int k, const double* __restrict__ list, double* __restrict__ pack) {
+    const bool live = st->status == ZB_OK && !st->done[k] && st->und[k] <= (double)ZB_GCAP;
+    const int cnt = live ? min(st->gcount[k], ZB_GCAP) : 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) pack[0] = (double)cnt;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ZB_GCAP; i += gridDim.x * blockDim.x)
+        pack[1 + i] = i < cnt ? list[(size_t)k * ZB_GCAP + i] : 0.0;
+}
+// the gathered packs of all ranks -> one list in rank order (the union holds und[k] <= ZB_GCAP elements)
+__global__ __launch_bounds__(1024) void k_zb_union(ZbState* __restrict__ st, int k, const double* __restrict__ packs, int world,
+                                                    double* __restrict__ list) {
+    if (st->status != ZB_OK || st->done[k] || st->und[k] > (double)ZB_GCAP) return;
+    __shared__ int off[65];
+    if (threadIdx.x == 0) {
+        int o = 0;
+        for (int r = 0; r < world; ++r) {
+            off[r] = o;
+            o += (int)packs[(size_t)r * (ZB_GCAP + 1)];
+        }
+        off[world] = o;
+        st->gcount[k] = o;
+    }
+    __syncthreads();
+    if (off[world] > ZB_GCAP) return;   // k_zb_finish reports the inconsistency
+    for (int r = 0; r < world; ++r) {
+        const int c = off[r + 1] - off[r];
+        for (int i = threadIdx.x; i < c; i += blockDim.x)
+            list[(size_t)k * ZB_GCAP + off[r] + i] = packs[(size_t)r * (ZB_GCAP + 1) + 1 + i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ objective
 // sum_k sigma_k loss(v_(k)) (objective.py:73-81) for banded sigma: the band sums of the losses need the keys at the last
 // rank of every band (the same select) and one pass; elements tied with a band-edge key are accounted for by their
@@ -1029,11 +1075,13 @@ int launch_zband(int loss, const ZbConfig& cfg, int64_t n, double rho, const u64
             if (loss == RBL_LOSS_BCE) {
                 hipLaunchKernelGGL(k_zb_eval<0>, dim3(hb), dim3(ZB_THREADS), 0, s, keys, (long long)n, (const ZbState*)st, cfg, k,
                                    rho, partials);
-                hipLaunchKernelGGL(k_zb_refine<0>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)partials, hb, last);
+                hipLaunchKernelGGL(k_zb_refine<0>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)partials, hb, last,
+                                   (double*)nullptr, (const double*)nullptr);
             } else {
                 hipLaunchKernelGGL(k_zb_eval<1>, dim3(hb), dim3(ZB_THREADS), 0, s, keys, (long long)n, (const ZbState*)st, cfg, k,
                                    rho, partials);
-                hipLaunchKernelGGL(k_zb_refine<1>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)partials, hb, last);
+                hipLaunchKernelGGL(k_zb_refine<1>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)partials, hb, last,
+                                   (double*)nullptr, (const double*)nullptr);
             }
         }
         if (loss == RBL_LOSS_BCE) {
@@ -1072,6 +1120,88 @@ int launch_zband_risk(int loss, const ZbConfig& cfg, int64_t n, const u64* keys,
         hipLaunchKernelGGL(k_zb_risk<1>, dim3(hb), dim3(ZB_THREADS), 0, s, keys, (long long)n, (const ZbState*)st, cfg, partials);
         hipLaunchKernelGGL(k_zb_risk_finish<1>, dim3(1), dim3(256), 0, s, (const ZbState*)st, cfg, (const double*)partials, hb, out_dev);
     }
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+// ---- the same steps one by one, for the multi-GPU driver (collectives in between; include/rbl.h: rbl_zbd_*)
+int launch_zbd_init(const ZbConfig& cfg, ZbState* st, u32* hist, hipStream_t s) {
+    hipLaunchKernelGGL(k_zb_init, dim3(1), dim3(1024), 0, s, st, cfg, hist);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zbd_hist(int64_t n, const u64* keys, ZbState* st, u32* hist, int pass, hipStream_t s) {
+    hipLaunchKernelGGL(k_zb_hist, dim3(zb_hist_blocks(n)), dim3(ZB_HTHREADS), 0, s, keys, (long long)n, (const ZbState*)st, hist, pass);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zbd_scan(int loss, const ZbConfig& cfg, ZbState* st, u32* hist, int pass, double rho, hipStream_t s) {
+    if (loss == RBL_LOSS_BCE)
+        hipLaunchKernelGGL(k_zb_scan<0>, dim3(1), dim3(1024), 0, s, st, cfg, hist, pass, rho, 1);
+    else
+        hipLaunchKernelGGL(k_zb_scan<1>, dim3(1), dim3(1024), 0, s, st, cfg, hist, pass, rho, 1);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+// local block sums of one root pass -> tot (4 * ZB_C doubles, to be summed over the ranks)
+int launch_zbd_eval(int loss, const ZbConfig& cfg, int64_t n, const u64* keys, ZbState* st, int k, double rho, double* partials,
+                    double* tot, hipStream_t s) {
+    const int hb = zb_eval_blocks(n);
+    if (loss == RBL_LOSS_BCE) {
+        hipLaunchKernelGGL(k_zb_eval<0>, dim3(hb), dim3(ZB_THREADS), 0, s, keys, (long long)n, (const ZbState*)st, cfg, k, rho, partials);
+        hipLaunchKernelGGL(k_zb_refine<0>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)partials, hb, 0, tot,
+                           (const double*)nullptr);
+    } else {
+        hipLaunchKernelGGL(k_zb_eval<1>, dim3(hb), dim3(ZB_THREADS), 0, s, keys, (long long)n, (const ZbState*)st, cfg, k, rho, partials);
+        hipLaunchKernelGGL(k_zb_refine<1>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)partials, hb, 0, tot,
+                           (const double*)nullptr);
+    }
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zbd_decide(int loss, const ZbConfig& cfg, ZbState* st, int k, double rho, const double* tot, int last, hipStream_t s) {
+    if (loss == RBL_LOSS_BCE)
+        hipLaunchKernelGGL(k_zb_refine<0>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)nullptr, 0, last,
+                           (double*)nullptr, tot);
+    else
+        hipLaunchKernelGGL(k_zb_refine<1>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)nullptr, 0, last,
+                           (double*)nullptr, tot);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zbd_gather(int loss, const ZbConfig& cfg, int64_t n, const u64* keys, ZbState* st, int k, double rho, double* partials,
+                      double* pack, hipStream_t s) {
+    double* glist = partials + 1024 * 4 * ZB_C;
+    const int hb = zb_eval_blocks(n);
+    if (loss == RBL_LOSS_BCE)
+        hipLaunchKernelGGL(k_zb_gather<0>, dim3(hb), dim3(ZB_THREADS), 0, s, keys, (long long)n, st, cfg, k, rho, glist);
+    else
+        hipLaunchKernelGGL(k_zb_gather<1>, dim3(hb), dim3(ZB_THREADS), 0, s, keys, (long long)n, st, cfg, k, rho, glist);
+    hipLaunchKernelGGL(k_zb_pack, dim3(8), dim3(256), 0, s, (const ZbState*)st, k, (const double*)glist, pack);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zbd_finish(int loss, const ZbConfig& cfg, ZbState* st, int k, double rho, double* partials, const double* packs_all,
+                      int world, hipStream_t s) {
+    double* glist = partials + 1024 * 4 * ZB_C;
+    hipLaunchKernelGGL(k_zb_union, dim3(1), dim3(1024), 0, s, st, k, packs_all, world, glist);
+    if (loss == RBL_LOSS_BCE)
+        hipLaunchKernelGGL(k_zb_finish<0>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)glist);
+    else
+        hipLaunchKernelGGL(k_zb_finish<1>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)glist);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+int launch_zbd_apply(int loss, const ZbConfig& cfg, int64_t n, double rho, const double* m, double* z, const double* lam, double* c,
+                     ZbState* st, int* pin, int seq, u32* counters, hipStream_t s) {
+    const int64_t ab = (n + ZB_THREADS * 8 - 1) / (ZB_THREADS * 8);
+    const unsigned ag = (unsigned)(ab < 1 ? 1 : (ab > 2048 ? 2048 : ab));
+    if (loss == RBL_LOSS_BCE)
+        hipLaunchKernelGGL(k_zb_apply<0>, dim3(ag), dim3(ZB_THREADS), 0, s, m, (long long)n, (const ZbState*)st, cfg, rho, z, lam, c, pin,
+                           seq, counters);
+    else
+        hipLaunchKernelGGL(k_zb_apply<1>, dim3(ag), dim3(ZB_THREADS), 0, s, m, (long long)n, (const ZbState*)st, cfg, rho, z, lam, c, pin,
+                           seq, counters);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

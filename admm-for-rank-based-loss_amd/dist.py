@@ -202,6 +202,37 @@ class GpuEngine:
     def zd_scatter(self, n):
         self.s.zd_scatter(n)
 
+    # sort-free z-step for banded rank weights (rbl_zbd_*): the views are what the driver sums / gathers
+    def zbd_begin(self):
+        return self.s.zbd_begin()
+
+    def zbd_hist(self, p):
+        from . import _lib
+        self.s.zbd_hist(p)
+        return self._zdv(_lib.BUF_ZB_HIST, "<i4")
+
+    def zbd_scan(self, p):
+        self.s.zbd_scan(p)
+
+    def zbd_eval(self, k):
+        from . import _lib
+        self.s.zbd_eval(k)
+        return self._zdv(_lib.BUF_ZB_TOT, "<f8")
+
+    def zbd_decide(self, k, last):
+        self.s.zbd_decide(k, last)
+
+    def zbd_gather(self, k):
+        from . import _lib
+        self.s.zbd_gather(k)
+        return self._zdv(_lib.BUF_ZB_PACK, "<f8")
+
+    def zbd_finish(self, k, packs_all, world):
+        self.s.zbd_finish(k, packs_all.data_ptr(), world)
+
+    def zbd_apply(self):
+        return self.s.zbd_apply()
+
 
 class ShardedADMM:
     """Drives one engine per rank through the phases with the collectives in between."""
@@ -227,6 +258,7 @@ class ShardedADMM:
         # a 1-rank group normally skips its (identity) all-reduces; bench.py --sharded-driver sets this
         # to issue them anyway and time the collective's launch path on a 1-GPU box
         self.always_allreduce = False
+        self.banded_z = os.environ.get("RBL_NO_ZBAND") != "1"   # sort-free z-step for banded rank weights where it applies
         self.n_coll = 0      # collectives issued in the iteration in flight
         self.n_sync = 0      # host waits of this driver in the iteration in flight (device -> host reads)
 
@@ -379,6 +411,29 @@ class ShardedADMM:
         self._alltoall(bu, recv_counts, zu, send_counts)
         e.zd_scatter(n_back)
 
+    ZB_ROOT_PASSES = 4   # (csrc/rbl_internal.h)
+
+    def _z_banded(self):
+        """z-step for rank weights that are constant on a few bands (superquantile, aorr, aorr_dc) WITHOUT a sort:
+        per select pass one sum of a 12 288-bin integer histogram, per root pass one sum of 64 doubles, one gather of
+        the <= 2048 undecided elements per band edge that can pool - no sample sort, no all-to-all, no merge tree
+        (include/rbl.h: rbl_zbd_*; csrc/zband.hip).  Every rank holds the same state throughout, so every rank reads
+        the same verdict: False = not applicable / not certified, the caller runs the sort-based z-step."""
+        e = self.e
+        ok, clusters = e.zbd_begin()
+        if not ok:
+            return False
+        for p in range(6):
+            self._allreduce(e.zbd_hist(p))
+            e.zbd_scan(p)
+        for k in clusters:
+            for r in range(self.ZB_ROOT_PASSES):
+                self._allreduce(e.zbd_eval(k))
+                e.zbd_decide(k, r == self.ZB_ROOT_PASSES - 1)
+            e.zbd_finish(k, self._gather_small(e.zbd_gather(k)), self.world)
+        self.n_sync += 1          # the verdict is read on the host
+        return e.zbd_apply() == 0
+
     def _risk_distributed(self):
         """sum_i sigma_i loss_(i) (objective.py:73-82) with the sorted losses partitioned over the
         ranks: the sample sort of the z-step on the loss keys, a dot product per chunk, one sum."""
@@ -412,7 +467,8 @@ class ShardedADMM:
         self._trace("step")
         e.phase_m()
         if e.sorted_path and self.world > 1 and self.dist_z:
-            self._z_distributed()
+            if not (self.banded_z and hasattr(e, "zbd_begin") and self._z_banded()):
+                self._z_distributed()
         else:
             m_all = None
             if e.sorted_path and self.world > 1:

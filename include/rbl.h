@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RBL_VERSION 102
+#define RBL_VERSION 103
 
 /* status codes */
 enum {
@@ -198,7 +198,11 @@ enum { RBL_BUF_M = 0, RBL_BUF_Q = 1, RBL_BUF_RED = 2, RBL_BUF_G = 3, RBL_BUF_V =
        RBL_BUF_ZD_BU = 22,     /* double x n_total their block values (send back)                  */
        RBL_BUF_ZD_ZIDS = 23,   /* int32 x n       row ids received back                            */
        RBL_BUF_ZD_ZU = 24,     /* double x n      block values received back                       */
-       RBL_BUF_ZD_COUNTS = 25  /* int64 x 64      rows of the local sorted run that go to each rank (rbl_zd_partition) */ };
+       RBL_BUF_ZD_COUNTS = 25, /* int64 x 64      rows of the local sorted run that go to each rank (rbl_zd_partition) */
+       /* sort-free z-step for banded rank weights, sharded rows (rbl_zbd_*) */
+       RBL_BUF_ZB_HIST = 26,   /* int32 x 12288   digit histograms of one select pass (to be SUMMED over the ranks)   */
+       RBL_BUF_ZB_TOT = 27,    /* double x 64     block sums of one root pass (to be SUMMED over the ranks)           */
+       RBL_BUF_ZB_PACK = 28    /* double x 2049   [count | undecided elements] of this rank (to be ALL-GATHERED)       */ };
 int  rbl_buffer(rbl_solver* h, int which, void** dev_ptr, int64_t* n_doubles);
 /* ---- distributed z-step for rank-weighted problems on several GPUs ---------------------------
  * (no reference counterpart: the reference is single-process; what is distributed is
@@ -242,6 +246,27 @@ int  rbl_zd_seam_sums(rbl_solver* h, int K, const void* cand_all_prev_dev, const
 int  rbl_zd_seam_fill(rbl_solver* h, const void* sums_total_dev);
 int  rbl_zd_return_partition(rbl_solver* h, int64_t nmax, int world, int64_t* counts);
 int  rbl_zd_scatter(rbl_solver* h, int64_t n_back);
+
+/* Distributed z-step WITHOUT a sort for rank weights that are constant on a few bands (superquantile, aorr, aorr_dc;
+ * src/optim/objective.py:108-145) - the reference's z_subproblem (algorithms.py:96-104) for row-sharded m.  No sample
+ * sort, no all-to-all, no merge tree: the keys at the band edges by a radix select on histograms summed over the ranks,
+ * the pooled block's value as the root of the pooled derivative from sums summed over the ranks, the last undecided
+ * elements gathered and settled identically on every rank.  After rbl_phase_m:
+ *   rbl_zbd_begin     *applicable = 0: not such weights / iteration 0 / pausing after an uncertified step -> rbl_zd_*.
+ *                     *root_clusters: bit k set = band edge k can pool.
+ *   for pass 0..5:    rbl_zbd_hist(pass); SUM RBL_BUF_ZB_HIST over the ranks; rbl_zbd_scan(pass)
+ *   for every set bit k, 4 times:  rbl_zbd_eval(k); SUM RBL_BUF_ZB_TOT; rbl_zbd_decide(k, last = 4th time)
+ *                     then rbl_zbd_gather(k); ALL-GATHER RBL_BUF_ZB_PACK; rbl_zbd_finish(k, gathered, world)
+ *   rbl_zbd_apply     z and c = z + lambda/rho of the local rows; *status = 0: certified (go on with rbl_phase_q),
+ *                     otherwise every rank got the same non-zero status: run rbl_zd_* for this iteration.            */
+int  rbl_zbd_begin(rbl_solver* h, int* applicable, int* root_clusters);
+int  rbl_zbd_hist(rbl_solver* h, int pass);
+int  rbl_zbd_scan(rbl_solver* h, int pass);
+int  rbl_zbd_eval(rbl_solver* h, int k);
+int  rbl_zbd_decide(rbl_solver* h, int k, int last);
+int  rbl_zbd_gather(rbl_solver* h, int k);
+int  rbl_zbd_finish(rbl_solver* h, int k, const void* packs_all_dev, int world);
+int  rbl_zbd_apply(rbl_solver* h, int* status);
 
 /* RBL_BUF_Q is the whole exchange buffer [q (ld) | D^T lambda seed (ld) | ||z||^2 | primal^2 |
  * sum loss]; RBL_BUF_RED is its 2-double tail.  After rbl_phase_q and after rbl_phase_dual this

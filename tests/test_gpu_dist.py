@@ -63,7 +63,7 @@ def _run(rank, world, port, cfg, out):
         for _ in range(cfg["iters"]):
             st = drv.step(True)
             hist.append((st.primal, st.dual, st.rho, st.objective))
-            flags.append((st.fused, st.mispredicted))
+            flags.append((st.fused, st.mispredicted, st.zband))
         state = s.get_state()
         extra = {}
         if world == 1 and cfg.get("oracle"):
@@ -131,8 +131,23 @@ def test_single_collective_erm_iteration_multi_rank(world, cfg, tmp_path):
     _check(cfg, world, tmp_path)
 
 
+BANDED_ENV = {"RBL_ZBAND_MIN_N": "16"}     # the sort-free z-step is taken from 65 536 rows on: forced onto these problems
+MORE += [
+    # rank weights that are constant on a few bands: the distributed z-step WITHOUT a sort (rbl_zbd_*: histograms and
+    # block sums summed over the ranks, the last undecided elements gathered) against the single-handle SORT path and
+    # the oracle
+    (4, dict(n=30001, d=33, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=12,
+             oracle=True, banded=True, env=BANDED_ENV)),
+    (3, dict(n=25000, d=21, wf="aorr", args=[0.2, 0.8], loss="hinge", reg=1e-4, wstep=2, iters=12, oracle=True, banded=True,
+             env=BANDED_ENV)),
+    (2, dict(n=20011, d=16, wf="aorr_dc", args=[15000, 3000], loss="binary_cross_entropy", reg=1e-4, wstep=2, iters=12,
+             oracle=True, banded=True, env=BANDED_ENV)),
+]
+
+
 @pytest.mark.parametrize("world,cfg", MORE, ids=["superq_w4", "aorr_hinge_w3", "ehrm_w4", "extremile_replicated_z",
-                                                  "erm_two_sweep_debug_env_w2", "tiny_with_an_empty_rank", "esrm_hinge_l1_w3"])
+                                                  "erm_two_sweep_debug_env_w2", "tiny_with_an_empty_rank", "esrm_hinge_l1_w3",
+                                                  "superq_sort_free_w4", "aorr_hinge_sort_free_w3", "aorr_dc_sort_free_w2"])
 def test_distributed_z_step_on_device(world, cfg, tmp_path):
     """rank-weighted problems with the sorted order partitioned over 3 / 4 ranks on the device path
     (rbl_zd_*: sample sort, chunk PAV, merge tree over ranks), and the replicated all-gather form."""
@@ -164,6 +179,13 @@ def _check(cfg, world, tmp_path):
 
 
 def _check_fused_and_oracle(cfg, one, rs, z_all):
+    if cfg.get("banded"):
+        # the sort-free distributed z-step ran (and was certified) on all but the first few iterations, on every rank alike
+        for r in rs:
+            modes = r["flags"][:, 2].tolist()
+            assert modes == rs[0]["flags"][:, 2].tolist()
+            assert modes[0] == 0 and modes.count(1) >= len(modes) - 4, modes
+        assert set(one["flags"][:, 2].tolist()) == {0}      # (the single-handle run is the sort path: no environment)
     if cfg.get("fused"):
         for r in rs:
             fl = r["flags"]
@@ -281,7 +303,7 @@ def _thread_rank(rank, world, cfg, hub, out, errs):
         for _ in range(cfg["iters"]):
             st = drv.step(True)
             hist.append((st.primal, st.dual, st.rho, st.objective))
-            flags.append((st.fused, st.mispredicted))
+            flags.append((st.fused, st.mispredicted, st.zband))
         state = s.get_state()
         out[rank] = dict(w=state["w"], z=state["z"], hist=np.array(hist), flags=np.array(flags))
     except BaseException as e:       # a dead thread must not leave the others in a barrier forever
@@ -297,8 +319,11 @@ def _thread_rank(rank, world, cfg, hub, out, errs):
     dict(n=40003, d=160, wf="erm", loss="binary_cross_entropy", reg=0.01, wstep=1, iters=9, storage="f64", fused=True,
          oracle=True),
     dict(n=16000, d=1000, wf="erm", loss="hinge", reg=0.01, wstep=2, iters=8, storage="f32", fused=True, oracle=True),
-], ids=["superq", "ehrm", "aorr_hinge", "erm_two_sweep", "erm_single_collective_f64", "erm_single_collective_f32_d1000"])
-def test_eight_ranks_as_threads_match_single_handle(cfg, tmp_path):
+    dict(n=50003, d=33, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=12, banded=True),
+    dict(n=30011, d=21, wf="aorr", args=[0.2, 0.8], loss="hinge", reg=1e-4, wstep=2, iters=12, banded=True),
+], ids=["superq", "ehrm", "aorr_hinge", "erm_two_sweep", "erm_single_collective_f64", "erm_single_collective_f32_d1000",
+        "superq_sort_free", "aorr_hinge_sort_free"])
+def test_eight_ranks_as_threads_match_single_handle(cfg, tmp_path, monkeypatch):
     """the 8-rank protocol (three levels of the merge tree over ranks, all-to-all exchanges; erm: the
     two-sweep iteration at d = 48, where the single-sweep kernel does not apply, and the single-collective
     iteration at d = 160 / 1000) on the device path against the single-handle run and the oracle"""
@@ -316,6 +341,8 @@ def test_eight_ranks_as_threads_match_single_handle(cfg, tmp_path):
     p.start(); p.join(300)
     assert p.exitcode == 0
     one = np.load(out1 % 0)
+    if cfg.get("banded"):
+        monkeypatch.setenv("RBL_ZBAND_MIN_N", "16")      # read by every rank's handle at its first z-step
     hub, out, errs = _Hub(world), [None] * world, []
     ts = [threading.Thread(target=_thread_rank, args=(r, world, cfg, hub, out, errs)) for r in range(world)]
     for t in ts:

@@ -59,5 +59,26 @@ drv._z_distributed()
 z_got = s.get_state()["z"]
 assert np.array_equal(z_ref, z_got), float(np.max(np.abs(z_ref - z_got)))
 print("distributed z-step through RCCL (1 rank): identical z")
+# the sort-free distributed z-step (rbl_zbd_*): its int32 histogram view and its float64 views through RCCL, same z as
+# the sort-based one to rounding (the pooled block is summed in another order)
+os.environ["RBL_ZBAND_MIN_N"] = "16"
+s2 = rbl.Solver(20000, 40, "superquantile", "binary_cross_entropy", reg=0.01, wstep=2, args=[0.5], n_total=20000,
+                row_offset=0, tol=0.0, storage="f32")
+e2 = GpuEngine(s2, 0)
+drv2 = ShardedADMM(e2)
+drv2.always_allreduce = True          # a 1-rank group normally skips its identity all-reduces: issue them
+drv2.setup_synthetic(seed=3)
+drv2.setup_gram()
+for _ in range(3):
+    drv2.step(False)
+e2.phase_m()
+assert drv2._z_banded(), "the sort-free z-step was not certified"
+z_fast = s2.get_state()["z"].copy()
+s2.set_state(z=np.zeros_like(z_fast))
+e2.phase_m()
+drv2._z_distributed()
+z_sort = s2.get_state()["z"]
+assert np.max(np.abs(z_fast - z_sort)) <= 1e-12 * max(1.0, np.max(np.abs(z_sort))), float(np.max(np.abs(z_fast - z_sort)))
+print("sort-free distributed z-step through RCCL (1 rank): int32 / float64 views accepted, same z")
 dist.destroy_process_group()
 print("OK")
