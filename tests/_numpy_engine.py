@@ -7,7 +7,7 @@ import types
 import numpy as np
 import torch
 
-from oracle import admm, prox, weights, wstep, objective, zdist
+from oracle import admm, prox, weights, wstep, objective, zband, zdist
 
 
 class NumpyEngine:
@@ -96,6 +96,55 @@ class NumpyEngine:
         v = np.sort(objective.sample_losses(self.loss, v_all.numpy()))
         return float(np.dot(self.sa, v))
 
+
+    # ---------------------------------------------------------------- sort-free distributed z-step (banded weights)
+    # oracle/zband.py: Passes restates rbl_zbd_* (csrc/zband.hip one step at a time); the tensors returned here are what
+    # dist.py: _z_banded sums / gathers over the ranks
+    banded_min_n = 16
+    n_banded = 0            # z-steps that ran sort-free and were certified
+
+    def zbd_begin(self):
+        if not hasattr(self, "_zb"):
+            self._zb = zband.Passes(self.loss, self.sa) if (self.sorted_path and self.wf != "ehrm") else None
+            self._zb_skip_until, self._zb_backoff = 0, 0
+        P = self._zb
+        if P is None or P.clusters is None or self.n_total < self.banded_min_n:
+            return False, []
+        if not (self.iter > 0 and self.iter >= self._zb_skip_until):
+            return False, []
+        P.begin(self.bufs["m"].numpy().copy(), self.rho)
+        return True, P.root_clusters()
+
+    def zbd_hist(self, p):
+        self._zb_hist = torch.from_numpy(self._zb.hist(p).copy())
+        return self._zb_hist
+
+    def zbd_scan(self, p):
+        self._zb.scan(p, self._zb_hist.numpy())
+
+    def zbd_eval(self, k):
+        self._zb_tot = torch.from_numpy(self._zb.eval(k).copy())
+        return self._zb_tot
+
+    def zbd_decide(self, k, last):
+        self._zb.decide(k, self._zb_tot.numpy(), last)
+
+    def zbd_gather(self, k):
+        return torch.from_numpy(self._zb.gather(k).copy())
+
+    def zbd_finish(self, k, packs_all, world):
+        self._zb.finish(k, packs_all.numpy(), world)
+
+    def zbd_apply(self):
+        z, status = self._zb.apply()
+        if status == zband.OK:
+            self.z = z
+            self._zb_backoff = 0
+            self.n_banded += 1
+        else:
+            self._zb_backoff = 2 if self._zb_backoff < 2 else (64 if self._zb_backoff >= 32 else 2 * self._zb_backoff)
+            self._zb_skip_until = self.iter + 1 + self._zb_backoff
+        return status
 
     # ---------------------------------------------------------------- distributed z-step
     # (same protocol as GpuEngine; the arithmetic is oracle/zdist.py)

@@ -107,6 +107,7 @@ def _worker(rank, world, port, cfg, out):
             eng = NumpyEngine(X[lo:lo + cnt], y[lo:lo + cnt], cfg["n"], lo, cfg["wf"], cfg["loss"], cfg["reg"], cfg["l1"],
                               B=cfg.get("B"), args=cfg.get("args"))
         drv = ShardedADMM(eng, dist_z=cfg.get("dist_z", True))
+        drv.banded_z = cfg.get("banded", False)      # the sort-free z-step for banded weights only where a case asks for it
         drv.setup_gram()
         hist = []
         for _ in range(cfg["iters"]):
@@ -114,7 +115,7 @@ def _worker(rank, world, port, cfg, out):
             hist.append((st.primal, st.dual, st.rho, st.objective))
         if rank == 0:
             np.savez(out, w=eng.w, hist=np.array(hist),
-                     fused=getattr(eng, "n_fused", 0), mispred=getattr(eng, "n_mispred", 0))
+                     fused=getattr(eng, "n_fused", 0), mispred=getattr(eng, "n_mispred", 0), banded=getattr(eng, "n_banded", 0))
     finally:
         dist.destroy_process_group()
 
@@ -162,6 +163,20 @@ def test_distributed_z_step_more_ranks(world, cfg, tmp_path):
     local PAV, merge tree over ranks: dist.py:_z_distributed on the NumPy engine), and the
     replicated all-gather form."""
     _check_sharded(cfg, world, tmp_path)
+
+
+@pytest.mark.parametrize("world,cfg", [
+    (3, dict(n=2001, d=9, seed=4, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, l1=False, iters=12)),
+    (4, dict(n=1603, d=7, seed=5, wf="aorr", args=[0.2, 0.8], loss="hinge", reg=1e-4, l1=False, iters=12)),
+    (2, dict(n=1500, d=8, seed=7, wf="aorr_dc", args=[1100, 200], loss="binary_cross_entropy", reg=1e-4, l1=False, iters=12)),
+    (4, dict(n=900, d=6, seed=9, wf="superquantile", args=[0.37], loss="hinge", reg=0.01, l1=True, iters=12)),
+], ids=["superq_world3", "aorr_hinge_world4", "aorr_dc_world2", "superq_0.37_hinge_l1_world4"])
+def test_sort_free_distributed_z_step(world, cfg, tmp_path):
+    """rank weights that are constant on a few bands: dist.py:_z_banded (histograms and block sums summed over the
+    ranks, the undecided elements gathered; oracle/zband.py:Passes restates rbl_zbd_* for the NumPy engine) over gloo
+    against the single-process oracle.  The sort-free path must have been certified on all but the first iterations."""
+    got = _check_sharded(dict(cfg, banded=True), world, tmp_path)
+    assert int(got["banded"]) >= cfg["iters"] - 4, int(got["banded"])
 
 
 def _check_sharded(cfg, world, tmp_path):

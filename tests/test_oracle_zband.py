@@ -89,3 +89,45 @@ def test_banded_z_step_against_the_reference_goldens():
         assert np.max(np.abs(z - zref.reshape(-1))) <= (1e-8 if cfg["loss"] == "binary_cross_entropy" else 1e-2), cfg
         seen += 1
     assert seen >= 2
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_pass_based_restatement_equals_exact_pav(world):
+    """oracle/zband.py:Passes (the steps of rbl_zbd_* / csrc/zband.hip: radix select on summed histograms, 16-candidate
+    root passes on summed block sums, the undecided elements gathered) on rows split over `world` ranks"""
+    rng = np.random.default_rng(5 + world)
+    certified = 0
+    for trial in range(60):
+        loss = ("binary_cross_entropy", "hinge")[trial % 2]
+        n = int(rng.choice([300, 2000, 9001]))
+        wf, args = (("superquantile", [0.5]), ("superquantile", [0.37]), ("aorr", [0.2, 0.8]),
+                    ("aorr_dc", [int(0.7 * n), int(0.1 * n)]))[trial % 4]
+        sigma, _ = weights.get_weights(wf, n, args)
+        spread = float(10.0 ** rng.uniform(-3, 1))
+        rho = float(np.max(sigma) / (spread * 10.0 ** rng.uniform(-3, 0.5)))
+        m = rng.normal(0.0, spread, n) + rng.choice([-1.0, 0.0, 1.5])
+        cuts = np.linspace(0, n, world + 1).astype(int)
+        ranks = [zband.Passes(loss, sigma) for _ in range(world)]
+        for r, P in enumerate(ranks):
+            P.begin(m[cuts[r]:cuts[r + 1]], rho)
+        for p in range(6):
+            h = sum(P.hist(p).astype(np.int64) for P in ranks)
+            for P in ranks:
+                P.scan(p, h)
+        for k in ranks[0].root_clusters():
+            for it in range(zband.ROOT_PASSES):
+                tot = sum(P.eval(k) for P in ranks)
+                for P in ranks:
+                    P.decide(k, tot, it == zband.ROOT_PASSES - 1)
+            packs = np.concatenate([P.gather(k) for P in ranks])
+            for P in ranks:
+                P.finish(k, packs, world)
+        outs = [P.apply() for P in ranks]
+        assert len({st for _, st in outs}) == 1                   # every rank reads the same verdict
+        if outs[0][1] != zband.OK:
+            continue
+        certified += 1
+        z = np.concatenate([zz for zz, _ in outs])
+        ref = _exact(loss, sigma, rho, m)
+        assert np.max(np.abs(z - ref)) <= 1e-10 * max(1.0, np.max(np.abs(ref))), (wf, loss, n, world)
+    assert certified >= 45, certified
