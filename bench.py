@@ -45,6 +45,9 @@ CONFIGS = {
                args=None, B=None, label="SRM erm / BCE / l1=0.01, synthetic 6000000x1000 (BASELINE configs[1])"),
     "C3": dict(rows=10_000_000, cols=1001, weight_function="aorr", loss="hinge", wstep=2, reg=1e-4,
                args=[0.2, 0.8], B=None, label="AoRR aorr[0.2,0.8] / hinge / l2=1e-4, synthetic 10000000x1001"),
+    "C3dc": dict(rows=10_000_000, cols=1001, weight_function="aorr_dc", loss="hinge", wstep=2, reg=1e-4,
+                 args=[8_000_000, 2_000_000], B=None,
+                 label="AoRR aorr_dc[k=8M,m=2M] / hinge / l2=1e-4, synthetic 10000000x1001 (the weights of run_AoRR_fixed.py)"),
     # one GPU's share of the 8-GPU configurations (BASELINE configs[3], configs[4]) as standalone problems
     "C4shard": dict(rows=6_250_000, cols=1000, weight_function="ehrm", loss="binary_cross_entropy", wstep=2, reg=0.01,
                     args=None, B=-5.0, label="EHRM ehrm / BCE / l2=0.01 / B=-5, synthetic 6250000x1000"),
