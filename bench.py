@@ -228,7 +228,7 @@ def c1_record(rbl, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--rows", type=int, default=0)
