@@ -387,7 +387,7 @@ int zb_setup(rbl_solver* h) {
     const char* off = getenv("RBL_NO_ZBAND");
     if (off && off[0] == '1') return RBL_OK;
     const char* mn = getenv("RBL_ZBAND_MIN_N");
-    const long long min_n = mn ? atoll(mn) : 65536;
+    const long long min_n = mn ? atoll(mn) : 4096;   // (6000 x 1000: 0.47 against 0.63 ms per iteration; below a few thousand rows nothing is gained)
     // (the configuration speaks of GLOBAL ranks: a row-sharded handle builds the same one; its driver runs the steps with
     // collectives in between - rbl_zbd_*)
     if (!h->sorted_path || h->cfg.weight_function == RBL_W_EHRM || h->nt < min_n || h->nt < 16) return RBL_OK;

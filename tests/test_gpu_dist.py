@@ -13,9 +13,10 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
+SORT_ENV = {"RBL_NO_ZBAND": "1"}     # banded weights would take the sort-free z-step from 4096 rows on: these cases test the sort-based one
 CFGS = [
     dict(n=40000, d=48, wf="erm", loss="binary_cross_entropy", reg=0.01, wstep=1, iters=8),
-    dict(n=30001, d=33, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=6),
+    dict(n=30001, d=33, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=6, env=SORT_ENV),
     dict(n=20000, d=21, wf="ehrm", B=-5.0, loss="binary_cross_entropy", reg=0.01, wstep=2, iters=5),
 ]
 
@@ -36,6 +37,8 @@ def _run(rank, world, port, cfg, out):
     # a rank that stops making progress reports where it stands and exits instead of hanging the suite
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("RBL_TEST_WATCHDOG_S", "240")), exit=True)
+    if world == 1:
+        os.environ["RBL_NO_ZBAND"] = "1"          # the single-handle reference run: sort + merge-tree PAV z-step
     if world > 1:
         os.environ.update(cfg.get("env", {}))     # only the sharded run: the single-handle run stays the plain path
         # This rig puts `world` processes on ONE GPU next to the test runner's own context.  With the HIP default of
@@ -83,8 +86,8 @@ MORE = [
     # oracle=True: the CPU oracle runs on the device-generated rows (get_D() / labels()) - the sub-sampled
     # parity of SURVEY 8c for generator data
     (4, dict(n=30001, d=33, wf="superquantile", args=[0.5], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=6,
-             oracle=True)),
-    (3, dict(n=25000, d=21, wf="aorr", args=[0.2, 0.8], loss="hinge", reg=1e-4, wstep=2, iters=6, oracle=True)),
+             oracle=True, env=SORT_ENV)),
+    (3, dict(n=25000, d=21, wf="aorr", args=[0.2, 0.8], loss="hinge", reg=1e-4, wstep=2, iters=6, oracle=True, env=SORT_ENV)),
     (4, dict(n=20000, d=21, wf="ehrm", B=-5.0, loss="binary_cross_entropy", reg=0.01, wstep=2, iters=5, oracle=True)),
     (2, dict(n=30001, d=33, wf="extremile", args=[2.0], loss="binary_cross_entropy", reg=0.01, wstep=2, iters=5,
              dist_z=False)),
@@ -131,7 +134,7 @@ def test_single_collective_erm_iteration_multi_rank(world, cfg, tmp_path):
     _check(cfg, world, tmp_path)
 
 
-BANDED_ENV = {"RBL_ZBAND_MIN_N": "16"}     # the sort-free z-step is taken from 65 536 rows on: forced onto these problems
+BANDED_ENV = {"RBL_ZBAND_MIN_N": "16"}     # (the sort-free z-step is taken from 4 096 rows on; forced all the same)
 MORE += [
     # rank weights that are constant on a few bands: the distributed z-step WITHOUT a sort (rbl_zbd_*: histograms and
     # block sums summed over the ranks, the last undecided elements gathered) against the single-handle SORT path and
@@ -343,6 +346,8 @@ def test_eight_ranks_as_threads_match_single_handle(cfg, tmp_path, monkeypatch):
     one = np.load(out1 % 0)
     if cfg.get("banded"):
         monkeypatch.setenv("RBL_ZBAND_MIN_N", "16")      # read by every rank's handle at its first z-step
+    else:
+        monkeypatch.setenv("RBL_NO_ZBAND", "1")          # these cases are about the sort-based distributed z-step
     hub, out, errs = _Hub(world), [None] * world, []
     ts = [threading.Thread(target=_thread_rank, args=(r, world, cfg, hub, out, errs)) for r in range(world)]
     for t in ts:

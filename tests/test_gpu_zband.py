@@ -1,5 +1,5 @@
 """The sort-free z-step for piecewise-constant rank weights (csrc/zband.hip; reference z_subproblem:
-src/optim/algorithms.py:96-104 + src/util/pav.py:84-161).  The fast path is taken from 65 536 rows on; here it is
+src/optim/algorithms.py:96-104 + src/util/pav.py:84-161).  The fast path is taken from 4 096 rows on; here it is
 forced onto small problems (RBL_ZBAND_MIN_N) and checked
 * against the CPU oracle's exact mode, iteration by iteration (the same bars as test_iterates_match_oracle_exact),
 * against the library's own sort + merge-tree PAV path on device-generated problems of 200 000 - 400 000 rows,
