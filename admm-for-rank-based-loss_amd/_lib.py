@@ -121,6 +121,7 @@ SIGNATURES = {
     "rbl_info": (C.c_int, [_P, _I64, C.POINTER(C.c_int), _D]),
     "rbl_kernel_time": (C.c_int, [_P, C.c_int, _D, _I64]),
     "rbl_reset_kernel_times": (C.c_int, [_P]),
+    "rbl_kernel_samples": (C.c_int, [_P, C.c_int, _P, C.c_int64, _I64]),
     "rbl_profile_kernels": (C.c_int, [_P, C.c_int]),
     "rbl_profile_sampling": (C.c_int, [_P, C.c_int]),
     "rbl_k_prox": (C.c_int, [C.c_int, C.c_int64, _P, C.c_double, _P, _P]),

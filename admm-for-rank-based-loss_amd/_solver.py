@@ -367,6 +367,14 @@ class Solver:
     def reset_kernel_times(self):
         _lib.check(self.lib.rbl_reset_kernel_times(self._h))
 
+    def kernel_samples(self, which):
+        """the timed launches of one kernel since the last reset, in launch order (ms)"""
+        cnt = C.c_int64(0)
+        _lib.check(self.lib.rbl_kernel_samples(self._h, int(which), None, 0, C.byref(cnt)))
+        out = np.empty(cnt.value)
+        _lib.check(self.lib.rbl_kernel_samples(self._h, int(which), _lib.ptr(out), cnt.value, C.byref(cnt)))
+        return out
+
     def kernel_time(self, which):
         ms, cnt = C.c_double(0), C.c_int64(0)
         _lib.check(self.lib.rbl_kernel_time(self._h, int(which), C.byref(ms), C.byref(cnt)))

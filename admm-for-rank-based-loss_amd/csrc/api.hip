@@ -72,6 +72,7 @@ struct rbl_solver {
     int profile_every = 1;   // kernel events on every profile_every-th iteration (rbl_profile_sampling)
     double kt_ms[3] = {0.0, 0.0, 0.0};
     int64_t kt_n[3] = {0, 0, 0};
+    std::vector<float> kt_samples[3];   // the timed launches one by one, in order (rbl_kernel_samples)
 
     // single-sweep erm iteration (sweep_erm.hip)
     bool fused_ok = false, z_ready = false, p_valid = false, p_pending = false, pred_valid = false, fused_ran = false;
@@ -1455,6 +1456,7 @@ int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
             if (hipEventElapsedTime(&t, h->kev[2 * k], h->kev[2 * k + 1]) == hipSuccess) {
                 h->kt_ms[k] += t;
                 h->kt_n[k] += 1;
+                if (h->kt_samples[k].size() < (size_t)1 << 16) h->kt_samples[k].push_back(t);
             }
             h->kev_pending[k] = false;
         }
@@ -1977,6 +1979,17 @@ int rbl_reset_kernel_times(rbl_solver* h) {
     RBL_ENTER_ITER(h);   // bookkeeping only: a w-step in flight stays
     h->kt_ms[0] = h->kt_ms[1] = h->kt_ms[2] = 0.0;
     h->kt_n[0] = h->kt_n[1] = h->kt_n[2] = 0;
+    for (auto& v : h->kt_samples) v.clear();
+    return RBL_OK;
+}
+
+int rbl_kernel_samples(rbl_solver* h, int which, double* out_ms, int64_t cap, int64_t* count) {
+    RBL_ENTER_ITER(h);   // bookkeeping only: a w-step in flight stays
+    if (which < 0 || which > 2 || cap < 0 || (cap > 0 && !out_ms)) return RBL_ERR_INVALID;
+    const std::vector<float>& v = h->kt_samples[which];
+    const int64_t k = (int64_t)v.size() < cap ? (int64_t)v.size() : cap;
+    for (int64_t i = 0; i < k; ++i) out_ms[i] = (double)v[(size_t)i];
+    if (count) *count = (int64_t)v.size();
     return RBL_OK;
 }
 

@@ -266,7 +266,12 @@ class ShardedADMM:
         if (self.world > 1 or self.always_allreduce) and t.numel() > 0:
             self.n_coll += 1
             self._trace("allreduce", t.numel())
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self._stage and t.is_cuda:          # gloo moves host memory: stage, like the gathers and the all-to-alls
+                h = t.cpu()                        # (gloo handed a device tensor runs copies on streams of its own)
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def _allgather_rows(self, local):
         """all-gather of an n_local vector -> n_total vector (valid prefix of a padded buffer)."""

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RBL_VERSION 103
+#define RBL_VERSION 104
 
 /* status codes */
 enum {
@@ -284,6 +284,11 @@ int  rbl_info(rbl_solver* h, int64_t* ld, int* num_cu, double* lipschitz);
 enum { RBL_KERNEL_GEMV = 0, RBL_KERNEL_GEMVT = 1, RBL_KERNEL_SWEEP_ERM = 2 };
 int  rbl_kernel_time(rbl_solver* h, int which, double* total_ms, int64_t* launches);
 int  rbl_reset_kernel_times(rbl_solver* h);
+/* The timed launches of one kernel since the last reset, one by one in launch order (milliseconds): the first
+ * min(cap, *count) of them are written to out_ms, *count is how many there are.  bench.py reports the first and
+ * the last of the timed region and the median of its last third beside the mean (the reference keeps a
+ * cumulative time stamp per iteration, algorithms.py:162; this is its per-launch counterpart). */
+int  rbl_kernel_samples(rbl_solver* h, int which, double* out_ms, int64_t cap, int64_t* count);
 /* enable: 0 = no HIP events inside the iteration (default: an event record costs ~5 us of stream
  * time), 1 = events around the sweep kernels (rbl_kernel_time), 2 = also around the phases (the
  * ms_* fields of rbl_stats, 0 otherwise) */

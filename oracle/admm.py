@@ -67,10 +67,11 @@ def z_step_faithful(weight_function, loss, sigma_a, sigma_b, B, rho, m):
 
 def admm_solve(X, y, weight_function="erm", loss="binary_cross_entropy", l2_reg=None, l1_reg=None,
                B=None, args=None, w0=None, max_iter=200, tol=1e-4, mode="exact", smooth=False,
-               t=1.0, store=True, use_c=True, w_tol=1e-14, timing=None):
+               t=1.0, store=True, use_c=True, w_tol=1e-14, timing=None, stamps=None):
     """Run the reference's solve loop.  Returns a Trace with per-iteration primal /
     dual residuals, rho (value used in the iteration), objective after the iteration,
-    and the final state (w, z, lam, rho, iters, converged)."""
+    and the final state (w, z, lam, rho, iters, converged).  stamps: a list that receives time.perf_counter() at
+    the start of the loop and at the end of every iteration (bench.py's cpu_baseline leg)."""
     if loss not in ("binary_cross_entropy", "hinge"):
         raise ValueError(
             f"Unrecognized loss '{loss}'! Options: ['binary_cross_entropy', 'multinomial_cross_entropy', 'hinge']")
@@ -101,6 +102,8 @@ def admm_solve(X, y, weight_function="erm", loss="binary_cross_entropy", l2_reg=
     v = D @ w
     converged = False
     it = 0
+    if stamps is not None:
+        stamps.append(time.perf_counter())
     for it in range(max_iter):
         t0 = time.perf_counter()
         # ---- z-step (:88-106)
@@ -159,10 +162,14 @@ def admm_solve(X, y, weight_function="erm", loss="binary_cross_entropy", l2_reg=
         tr.rho.append(rho)
         if primal < tol and dual < tol:                    # :137-141
             converged = True
+            if stamps is not None:
+                stamps.append(time.perf_counter())
             break
         rho = next_rho(rho, primal, d)                     # :154-157
         if store:
             tr.objective.append(F(w, v))                   # :159-161
+        if stamps is not None:
+            stamps.append(time.perf_counter())
         if smooth and it >= 17:                            # :254-255
             t = max(t * 0.9, 1e-9) % np.power(rho, -0.1) * np.power(float(it), -0.1)
     if smooth and w_flag == 1:                             # :257-258

@@ -46,7 +46,8 @@ def _run(rank, world, port, cfg, out):
         # collective every few microseconds) then stall for good in a device wait of one rank (seen with 4 ranks of
         # n = 5 / n = 64 after in-process GPU tests; every rank on one queue: clean).  One process per GPU - the real
         # deployment - never gets there.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
+        if os.environ.get("RBL_TEST_QUEUE_LIMIT", "1") != "0":
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
     import torch
     import torch.distributed as dist
     import admm_for_rank_based_loss_amd as rbl

@@ -14,6 +14,13 @@ the device:
   full v; primal / dual residuals equal their NumPy restatement from the pulled vectors.
 * shard-count invariance at full size: a 2-handle row-sharded run (ShardedADMM, ranks as threads with hub
   collectives) reproduces primal / dual / rho / objective of the single handle.
+
+Which z-step was checked is part of the test: `rbl_stats.zband` is recorded per iteration and
+asserted - C2sq and C3 must have had BOTH a certified sort-free z (mode 1, csrc/zband.hip) and a sort + merge-tree
+PAV z (mode 0 / 2, csrc/sort.hip + pav.hip) through the KKT check; C2sq_sort pins the sorted path at 6 M positions
+with RBL_NO_ZBAND=1.  C4shard (EHRM, 6.25 M rows: sort + both-branch prox + merge-tree PAV where the CPT weights pool
+everywhere, src/util/PAV_cpt.py:169-293) and C5shard (1.25 M x 10 000 through the workgroup-per-row kernel
+k_sweep_erm_wide) are one GPU's share of BASELINE configs[3] / configs[4] - the kernels those bench lines time.
 """
 import threading
 
@@ -29,7 +36,16 @@ CFG = {
     "C2sq": dict(n=6_000_000, d=1000, wf="superquantile", loss="binary_cross_entropy", wstep=2, reg=0.01, args=[0.5]),
     # BASELINE configs[2]: AoRR, intercept column -> d = 1001, hinge
     "C3": dict(n=10_000_000, d=1001, wf="aorr", loss="hinge", wstep=2, reg=1e-4, args=[0.2, 0.8]),
+    # C2sq with the sort-free z-step switched off: radix sort + merge-tree PAV + scatter at 6 M positions
+    "C2sq_sort": dict(n=6_000_000, d=1000, wf="superquantile", loss="binary_cross_entropy", wstep=2, reg=0.01, args=[0.5],
+                      env={"RBL_NO_ZBAND": "1"}, nit=4),
+    # one GPU's share of BASELINE configs[3]: EHRM (CPT weights: smooth, so the z-step keeps the sort)
+    "C4shard": dict(n=6_250_000, d=1000, wf="ehrm", loss="binary_cross_entropy", wstep=2, reg=0.01, args=None, B=-5.0, nit=4),
+    # one GPU's share of BASELINE configs[4]: d = 10 000 -> the workgroup-per-row single-sweep kernel
+    "C5shard": dict(n=1_250_000, d=10_000, wf="erm", loss="binary_cross_entropy", wstep=1, reg=0.01, args=None, nit=4,
+                    sub_rows=20_000),
 }
+NIT = {"C2": 3, "C2sq": 10, "C3": 10}
 SEED = 17
 SUB_ROWS, SUB_OFF = 50_000, 1_234_567
 
@@ -51,9 +67,18 @@ def _dloss(loss, x):
     return (x > -1.0).astype(np.float64), (x >= -1.0).astype(np.float64)
 
 
-def check_isotonic_kkt(loss, sigma, rho, m_sorted, z_sorted, rtol=1e-9):
-    """KKT of the generalised isotonic problem on every block of equal z (see the module docstring)."""
+def check_isotonic_kkt(loss, sigma, rho, m_sorted, z_sorted, rtol=1e-9, lower=None, upper=None):
+    """KKT of the generalised isotonic problem on every block of equal z (see the module docstring).
+    lower / upper: a one-sided bound u_i >= lower (u_i <= upper) on top of the order constraints - EHRM's
+    z = max(B, PAV(sigma_b, m)) / min(B, PAV(sigma_a, m)) (PAV_cpt.py:205-226; clipping commutes with PAV for a
+    one-sided bound).  The block sitting ON the bound cannot move through it, so only the directions
+    that stay feasible are tested there: at a lower bound no suffix may want to move up, at an upper bound no prefix
+    may want to move down."""
     n = z_sorted.shape[0]
+    if lower is not None:
+        assert np.all(z_sorted >= lower)
+    if upper is not None:
+        assert np.all(z_sorted <= upper)
     assert np.all(np.diff(z_sorted) >= 0), "z is not monotone in the sorted order of m"
     starts = np.flatnonzero(np.concatenate(([True], z_sorted[1:] != z_sorted[:-1])))
     dl, dr = _dloss(loss, z_sorted)
@@ -64,7 +89,10 @@ def check_isotonic_kkt(loss, sigma, rho, m_sorted, z_sorted, rtol=1e-9):
     tol_i = rtol * scale[bid] + 1e-300
     # whole block: sum of left derivatives <= 0 <= sum of right derivatives
     tl, tr_ = np.add.reduceat(gl, starts), np.add.reduceat(gr, starts)
-    assert np.all(tl <= rtol * scale + 1e-300) and np.all(tr_ >= -rtol * scale - 1e-300), \
+    zb = z_sorted[starts]
+    on_lo = (zb == lower) if lower is not None else np.zeros(zb.shape, dtype=bool)
+    on_hi = (zb == upper) if upper is not None else np.zeros(zb.shape, dtype=bool)
+    assert np.all((tl <= rtol * scale + 1e-300) | on_lo) and np.all((tr_ >= -rtol * scale - 1e-300) | on_hi), \
         (float(np.max(tl / scale)), float(np.min(tr_ / scale)))
     # prefixes must not want to move down: sum_{i <= k in block} gl_i <= 0
     cl = np.cumsum(gl)
@@ -72,7 +100,7 @@ def check_isotonic_kkt(loss, sigma, rho, m_sorted, z_sorted, rtol=1e-9):
     # cumulative sums over n terms carry ~n eps of the largest prefix: compare on a per-block restart
     pre = cl - base
     err_guard = 64 * np.finfo(float).eps * np.maximum.accumulate(np.abs(cl))
-    assert np.all(pre <= tol_i + err_guard), float(np.max((pre - err_guard) / scale[bid]))
+    assert np.all((pre <= tol_i + err_guard) | on_lo[bid]), float(np.max((pre - err_guard) / scale[bid]))
     # suffixes must not want to move up: sum_{i >= k in block} gr_i >= 0  <=>  total_r - prefix_r(before k) >= 0
     cr = np.cumsum(gr)
     base_r = np.concatenate(([0.0], cr))[starts][bid]
@@ -80,7 +108,7 @@ def check_isotonic_kkt(loss, sigma, rho, m_sorted, z_sorted, rtol=1e-9):
     before[starts] = 0.0
     suf = tr_[bid] - before
     err_guard_r = 64 * np.finfo(float).eps * np.maximum.accumulate(np.abs(cr))
-    assert np.all(suf >= -tol_i - err_guard_r), float(np.min((suf + err_guard_r) / scale[bid]))
+    assert np.all((suf >= -tol_i - err_guard_r) | on_hi[bid]), float(np.min((suf + err_guard_r) / scale[bid]))
     return starts.shape[0]
 
 
@@ -146,7 +174,7 @@ def _sharded_rank(R, rank, world, cfg, nit, hub, out, errs):
         torch.cuda.set_device(0)
         lo, cnt, _ = shard_rows(cfg["n"], world, rank)
         s = R.Solver(cnt, cfg["d"], cfg["wf"], cfg["loss"], reg=cfg["reg"], wstep=cfg["wstep"], args=cfg["args"],
-                     n_total=cfg["n"], row_offset=lo, tol=0.0, storage="f32")
+                     B=cfg.get("B"), n_total=cfg["n"], row_offset=lo, tol=0.0, storage="f32")
         drv = _hub_driver(ShardedADMM, hub)(GpuEngine(s, 0), world=world, rank=rank)
         drv.setup_synthetic(SEED)
         drv.setup_gram()
@@ -161,16 +189,20 @@ def _sharded_rank(R, rank, world, cfg, nit, hub, out, errs):
         hub["bar"].abort()
 
 
-@pytest.mark.parametrize("name", ["C2", "C2sq", "C3"])
-def test_full_size_properties(R, name):
+@pytest.mark.parametrize("name", ["C2", "C2sq", "C3", "C2sq_sort", "C4shard", "C5shard"])
+def test_full_size_properties(R, name, monkeypatch):
     import torch
     from admm_for_rank_based_loss_amd.dist import GpuEngine
-    from oracle import objective as oobj, weights
+    from oracle import objective as oobj, weights, pav as opav
     cfg = CFG[name]
+    for k, val in cfg.get("env", {}).items():
+        monkeypatch.setenv(k, val)          # read by the handle at its first rank-weighted z-step
     n, d = cfg["n"], cfg["d"]
-    loss, rw = cfg["loss"], cfg["wf"] != "erm"
-    nit = 3
-    s = R.Solver(n, d, cfg["wf"], loss, reg=cfg["reg"], wstep=cfg["wstep"], args=cfg["args"], tol=0.0, storage="f32")
+    loss, rw, ehrm = cfg["loss"], cfg["wf"] != "erm", cfg["wf"] == "ehrm"
+    nit = cfg.get("nit", NIT.get(name, 3))
+    sub_rows = cfg.get("sub_rows", SUB_ROWS)
+    B = cfg.get("B")
+    s = R.Solver(n, d, cfg["wf"], loss, reg=cfg["reg"], wstep=cfg["wstep"], args=cfg["args"], B=B, tol=0.0, storage="f32")
     eng = GpuEngine(s, 0)          # library kernels on torch's stream: the views below are ordered with them
     s.generate_synthetic(SEED)
     s.gram()
@@ -178,17 +210,19 @@ def test_full_size_properties(R, name):
     def pull(which):
         return eng.buf(which).cpu().numpy().copy()
 
-    sigma = weights.get_weights(cfg["wf"], n, cfg["args"])[0]
-    dev_sigma = s.sigma()[0]
-    assert np.allclose(dev_sigma, sigma, rtol=1e-13, atol=1e-300)     # sigma generator at full size (objective.py:97-136)
+    sigma, sigma_b = weights.get_weights(cfg["wf"], n, cfg["args"])
+    dev_sigma = s.sigma()
+    assert np.allclose(dev_sigma[0], sigma, rtol=1e-13, atol=1e-300)  # sigma generator at full size (objective.py:97-136)
+    if ehrm:
+        assert np.allclose(dev_sigma[1], sigma_b, rtol=1e-13, atol=1e-300)           # CPT weights (objective.py:148-164)
 
-    hist = []
+    hist, modes, kkt_modes, branches = [], [], [], []
     for it in range(nit):
         st0 = s.get_state()
         lam0, rho = st0["lam"], st0["rho"]
         s.phase_m()
         s.phase_z()
-        z = s.get_state(want_lam=False)["z"]
+        z = s.get_state(want_lam=False)["z"]     # (reading z settles a sort-free z-step: certified, or redone with the sort)
         # ---- z-step properties.  m = v - lambda/rho with the v the iteration used
         v_prev = pull("v") if (it > 0 or rw) else None
         if v_prev is None:
@@ -199,7 +233,22 @@ def test_full_size_properties(R, name):
                 assert np.array_equal(m, pull("m"))      # k_make_m: bit-exact restatement
         if rw:
             order = np.argsort(m, kind="stable")
-            nblocks = check_isotonic_kkt(loss, sigma, rho, m[order], z[order])
+            if ehrm:
+                # z = max(B, PAV(sigma_b, m)) or min(B, PAV(sigma_a, m)): the branch is whichever side of B the
+                # whole vector sits on; KKT with that branch's weights and the one-sided bound
+                zs = z[order]
+                br = 1 if np.all(zs >= B) else 0
+                assert br == 1 or np.all(zs <= B)
+                nblocks = check_isotonic_kkt(loss, sigma_b if br else sigma, rho, m[order], zs,
+                                             lower=B if br else None, upper=None if br else B)
+                branches.append(br)
+                if it in (0, nit - 1):
+                    # the choice itself = the reference's singleton-stage scalar test (PAV_cpt.py:205-226)
+                    # recomputed in NumPy with exact element solves
+                    want = opav.ehrm_branch_exact(sigma, sigma_b, B, rho, m[order])
+                    assert br == (0 if want == "a" else 1), (it, br, want)
+            else:
+                nblocks = check_isotonic_kkt(loss, sigma, rho, m[order], z[order])
             assert 1 <= nblocks <= n
         else:
             # erm: every row its own block (prox is monotone in m for a constant sigma)
@@ -212,6 +261,9 @@ def test_full_size_properties(R, name):
         s.phase_dual(True)
         st = s.phase_finish()
         hist.append((st.primal, st.dual, st.rho, st.objective))
+        modes.append(int(st.zband))
+        if ehrm:
+            assert int(st.ehrm_branch) == branches[-1]
         # ---- dual update, residuals, objective from the pulled vectors
         new = s.get_state()
         w, v = new["w"], pull("v")
@@ -220,18 +272,32 @@ def test_full_size_properties(R, name):
         assert abs(st.primal - np.linalg.norm(z - v)) <= 1e-10 * max(1.0, st.primal)
         assert abs(st.dual - np.linalg.norm(w - st0["w"])) <= 1e-10 * max(1.0, st.dual)
         kwreg = dict(l1_reg=cfg["reg"]) if cfg["wstep"] == 1 else dict(l2_reg=cfg["reg"])
-        f_ref = oobj.objective_from_v(loss, sigma, v, w, **kwreg)
+        f_ref = oobj.objective_from_v(loss, sigma, v, w, **kwreg)     # (EHRM too: betas = alphas, objective.py:76)
         assert abs(st.objective - f_ref) <= 1e-10 * max(1.0, abs(f_ref)), (st.objective, f_ref)
         if it == nit - 1:
             w_last, v_last = w, v
+    # ---- which z-step the KKT check above has seen (rbl_stats.zband: 0 sort + PAV, 1 sort-free and certified,
+    # 2 sort-free, not certified, redone with the sort; -1 erm)
+    if name in ("C2sq", "C3"):
+        assert modes[0] == 0, modes                       # iteration 0: every m equal, the fast path is skipped outright
+        # both paths went through the KKT check above: certified sort-free z-steps (the first few attempts pool most
+        # rows into one block and are redone with the sort, then the fast path pauses for 2, 4, ... iterations)
+        assert modes.count(1) >= 3 and (0 in modes or 2 in modes), modes
+        assert modes[-1] == 1, modes                      # ... and the steady state is the sort-free one
+    elif name == "C2sq_sort":
+        assert modes == [0] * nit, modes                  # RBL_NO_ZBAND=1: radix sort + merge-tree PAV every time
+    elif ehrm:
+        assert modes == [0] * nit, modes                  # CPT weights are smooth: EHRM keeps the sort
+    else:
+        assert modes == [-1] * nit, modes
     hist = np.array(hist)
 
     # ---- v = D w on two 50 000-row slices (one near the start, one at the END of the matrix: a launch that
     # wraps at 2^32 threads leaves the tail rows wrong) regenerated by the counter-based generator with the
     # GLOBAL column statistics of the full matrix (the generator gives the same rows under any sharding)
     y_full = s.labels()
-    for sub_off in (SUB_OFF, n - SUB_ROWS - 321):
-        sub = R.Solver(SUB_ROWS, d, cfg["wf"], loss, reg=cfg["reg"], wstep=cfg["wstep"], args=cfg["args"], n_total=n,
+    for sub_off in (min(SUB_OFF, n // 5), n - sub_rows - 321):
+        sub = R.Solver(sub_rows, d, cfg["wf"], loss, reg=cfg["reg"], wstep=cfg["wstep"], args=cfg["args"], B=B, n_total=n,
                        row_offset=sub_off, tol=0.0, storage="f32")
         sub_eng = GpuEngine(sub, 0)
         sub.synth_local(SEED)
@@ -240,9 +306,9 @@ def test_full_size_properties(R, name):
         sub.synth_finish()
         Dsub = sub.get_D()
         ysub = sub.labels()
-        assert np.array_equal(ysub, y_full[sub_off:sub_off + SUB_ROWS])
+        assert np.array_equal(ysub, y_full[sub_off:sub_off + sub_rows])
         v_sub = Dsub @ w_last
-        got = v_last[sub_off:sub_off + SUB_ROWS]
+        got = v_last[sub_off:sub_off + sub_rows]
         # fp64 accumulation of d products, different summation order: d * eps * sum |a||b|
         bound = 4 * d * np.finfo(float).eps * (np.abs(Dsub) @ np.abs(w_last)) + 1e-300
         assert np.all(np.abs(got - v_sub) <= bound), (sub_off, float(np.max(np.abs(got - v_sub) / bound)))

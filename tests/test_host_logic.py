@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # the Python binding covers the same set
     assert declared == set(rbl._lib.SIGNATURES), declared ^ set(rbl._lib.SIGNATURES)
-    assert lib.rbl_version() == 103
+    assert lib.rbl_version() == 104
 
 
 def test_no_cpu_fallback_without_device():

@@ -335,3 +335,30 @@ def test_philox_known_answers_and_generator_restatement():
     assert np.max(np.abs(Xstd.mean(axis=0))) < 1e-12 and np.max(np.abs(Xstd.std(axis=0) - 1)) < 1e-12
     # the class-separating column carries the label: a linear classifier on it beats 70 %
     assert np.mean(np.sign(Xstd[:, special[0]]) == yd) > 0.7
+
+
+def test_bounded_kkt_checker_of_the_full_size_tests():
+    """tests/test_gpu_fullsize.py checks EHRM at 6.25 M rows through the KKT conditions of the order- and
+    bound-constrained problem (z = max(B, PAV(sigma_b, m)) / min(B, PAV(sigma_a, m)), PAV_cpt.py:205-226).  The checker
+    itself is pinned here on the oracle's exact EHRM z-step: it accepts both branches and rejects the wrong branch's
+    weights and a block moved by 1e-6."""
+    from test_gpu_fullsize import check_isotonic_kkt
+    from oracle import weights, pav
+    rng = np.random.default_rng(0)
+    n = 3000
+    sa, sb = weights.get_weights("ehrm", n)
+    for B, shift, rho in ((-5.0, 0.0, 1e-4), (-5.0, -6.0, 1e-2), (0.5, 0.0, 1e-4)):
+        m = np.sort(rng.normal(size=n) * 2 + shift)
+        for br in ("a", "b"):
+            z, _ = pav.ehrm_exact(sa, sb, B, rho, m, branch=br)
+            good, bad = (sb, sa) if br == "b" else (sa, sb)
+            kw = dict(lower=B) if br == "b" else dict(upper=B)
+            assert check_isotonic_kkt("binary_cross_entropy", good, rho, m, z, **kw) >= 1
+            if np.mean(z == B) < 0.6:     # (with nearly everything on the bound little is left to tell the weights apart)
+                with pytest.raises(AssertionError):
+                    check_isotonic_kkt("binary_cross_entropy", bad, rho, m, z, **kw)
+            z2 = z.copy()
+            k = n // 2
+            z2[z2 == z2[k]] += 1e-6 * (1 + abs(z2[k]))
+            with pytest.raises(AssertionError):
+                check_isotonic_kkt("binary_cross_entropy", good, rho, m, np.maximum.accumulate(z2), **kw)
