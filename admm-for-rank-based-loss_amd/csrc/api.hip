@@ -263,6 +263,8 @@ int alloc_wstep(WstepWorkspace& ww, int64_t ld) {
     RBL_TRY(dev_alloc(&ww.p, (size_t)ld));
     RBL_TRY(dev_alloc(&ww.scal, 8));
     RBL_TRY(dev_alloc(&ww.flags, 8));
+    RBL_TRY(dev_alloc(&ww.bar, (size_t)WSTEP_BAR_UINTS));
+    RBL_HIP(hipMemset(ww.bar, 0, sizeof(unsigned) * WSTEP_BAR_UINTS));
     RBL_TRY(alloc_wstep_pin(ww));
     return RBL_OK;
 }
@@ -271,6 +273,7 @@ void free_wstep(WstepWorkspace& ww) {
     dev_free(ww.eig_Vt); dev_free(ww.eig_V); dev_free(ww.eig_lambda);
     dev_free(ww.yk); dev_free(ww.Gy); dev_free(ww.wn); dev_free(ww.r); dev_free(ww.p); dev_free(ww.scal);
     dev_free(ww.flags);
+    dev_free(ww.bar);
     free_wstep_pin(ww);
     ww = WstepWorkspace{};
 }
@@ -1224,9 +1227,12 @@ static int phase_w_body(rbl_solver* h) {
     // the active-set lasso kernel leaves G w of its solution in ww.Gy (it needs the gradient for its
     // own optimality test): no d x d product for the rho prediction unless FISTA had to take over
     bool gw_ready = predict && wstep == RBL_WSTEP_L1;
-    if (!spec)
+    if (!spec) {
         RBL_TRY(run_wstep(wstep, h->G, h->ld, h->q, h->step_rho, h->cfg.reg, h->smooth_t, h->L, h->cfg.w_tol, 100000,
-                          h->w, h->ww, &h->inner_iters, h->stream, &fs_pending, nullptr, h->w_prev, gw_ready));
+                          h->w, h->ww, &h->inner_iters, h->stream, &fs_pending, nullptr, h->w_prev, predict));
+        // the persistent CG / nonlinear-CG kernels leave G w of their solution in ww.Gy as well
+        if (wstep != RBL_WSTEP_L1) gw_ready = predict && h->ww.gw_valid;
+    }
     auto after_w = [&]() -> int {
         if (predict) {
             if (!gw_ready) RBL_TRY(launch_symv(h->G, h->ld, h->w, h->ww.Gy, h->stream));
@@ -2329,7 +2335,9 @@ int rbl_k_wstep(int wstep, int64_t d, const double* G, const double* q, double r
     ww.p = sc.alloc<double>((size_t)ld);
     ww.scal = sc.alloc<double>(8);
     ww.flags = sc.alloc<int>(8);
-    SC_CHECK(ww.yk && ww.Gy && ww.wn && ww.r && ww.p && ww.scal && ww.flags);
+    ww.bar = sc.alloc<unsigned>((size_t)WSTEP_BAR_UINTS);
+    SC_CHECK(ww.yk && ww.Gy && ww.wn && ww.r && ww.p && ww.scal && ww.flags && ww.bar);
+    RBL_HIP(hipMemsetAsync(ww.bar, 0, sizeof(unsigned) * WSTEP_BAR_UINTS, sc.s));
     RBL_TRY(alloc_wstep_pin(ww));
     struct PinGuard {
         WstepWorkspace& w;

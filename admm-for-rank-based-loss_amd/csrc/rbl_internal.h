@@ -192,7 +192,13 @@ struct WstepWorkspace {
     bool eig_ok;
     int last_iters; // CG iterations of the previous w-step (sizes the next batch)
     int last_fista; // the same for FISTA; pin[6..7] = its (done, iterations)
+    // persistent one-launch w-steps (wstep.hip: k_cg_persist / k_ncg_persist): two sets of barrier counters used
+    // alternately (a launch clears the set of the next one), pin[4..5] / pin[8..9] = their (status, iterations)
+    unsigned* bar;
+    int bar_parity;
+    bool gw_valid;  // ws.Gy holds G w of the w the last run_wstep returned
 };
+constexpr int WSTEP_BAR_UINTS = 2 * 10 * 32;
 int launch_power_iteration(const double* G, int64_t d, double* tmp1, double* tmp2, double* scal, int iters,
                            double* lambda_host, hipStream_t s);
 // lasso / smoothed-l1 by FISTA with restart, ridge by CG; w is updated in place.

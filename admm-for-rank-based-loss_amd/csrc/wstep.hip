@@ -516,13 +516,38 @@ int run_fista(int mode, const double* G, int64_t ld, const double* q, double rho
 }
 
 
+struct WpPlan;
+bool ncg_persist_try(const double* G, int64_t ld, const double* q, NcgParams P, int max_iter, double* w,
+                     WstepWorkspace& ws, bool want_Gw, int* status, int* iters, hipStream_t s, int* rc);
+
 // smoothed-l1 w-step by preconditioned nonlinear CG with exact line search (k_ncg_*), batched like the CG:
 // about as many iterations as last time per host round trip.  Falls back to FISTA (which has no line
 // search to fail) if the cap is reached.
 int run_ncg(const double* G, int64_t ld, const double* q, double rho, double reg, double smooth_t, double L, double tol,
-            int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s) {
+            int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s, bool want_Gw) {
     const unsigned sg = symv_grid(ld);
     NcgParams P{rho, reg, smooth_t, tol};
+    {
+        // one persistent launch (k_ncg_persist) where the row width allows it
+        int status = 0, it = 0, rc = RBL_OK;
+        if (ncg_persist_try(G, ld, q, P, max_inner < 600 ? max_inner : 600, w, ws, want_Gw, &status, &it, s, &rc)) {
+            RBL_TRY(rc);
+            if (status == 1) {
+                ws.last_fista = it;
+                ws.gw_valid = want_Gw;
+                if (iters_host) *iters_host = it;
+                return RBL_OK;
+            }
+            if (status < 0) {
+                rbl_set_error("w-step: the persistent nonlinear-CG kernel did not complete (status %d)", status);
+                return RBL_ERR_HIP;
+            }
+            int more = 0;      // iteration cap: FISTA takes over from the w reached, as on the batched path
+            RBL_TRY(run_fista(1, G, ld, q, rho, reg, smooth_t, L, tol, max_inner, w, ws, &more, s));
+            if (iters_host) *iters_host = it + more;
+            return RBL_OK;
+        }
+    }
     double *p = ws.p, *sv = ws.r, *Gp = ws.Gy, *Gw = ws.wn, *gdiag = ws.yk;
     hipLaunchKernelGGL(k_symv, dim3(sg), dim3(256), 0, s, G, (long long)ld, w, Gw, 1.0, 0.0, (const int*)nullptr);
     hipLaunchKernelGGL(k_ncg_init, dim3(1), dim3(UPD_THREADS), 0, s, (long long)ld, G, Gw, q, w, P, p, sv, gdiag, ws.scal,
@@ -565,10 +590,497 @@ int run_ncg(const double* G, int64_t ld, const double* q, double rho, double reg
 
 }  // namespace
 
+namespace {
+
+// ============================================================================================
+// One persistent kernel per d-space w-step (round 3).  The batched path above spends ~5 us per launch whatever
+// the kernel does (CG: 2 + 2 k launches, nonlinear CG the same), i.e. 0.15 ms (CG) / 0.2-0.6 ms (NCG) per ADMM
+// iteration at d = 1000 for a few microseconds of arithmetic.  Here the whole w-step is ONE launch:
+//   * block b owns `rpb` consecutive rows of G, staged ONCE into its LDS (16 rows x 1000 doubles = 128 KB): per inner
+//     iteration it computes its rows of G p from LDS and writes them to an exchange buffer;
+//   * ONE device-wide barrier per inner iteration (hierarchical: a counter per group of blocks, then a top counter;
+//     release / acquire fences at agent scope around it), after which every block reads the whole product (8 KB)
+//     and performs the REST of the iteration - dot products, step length, vector updates, the exact line search of
+//     the nonlinear CG - redundantly on vectors it keeps in registers.  Identical arithmetic on identical inputs in a
+//     fixed order: every block holds the same bits, so convergence is decided identically everywhere and no flag has
+//     to be exchanged; standard CG / NCG arithmetic, nothing pipelined or reordered across iterations;
+//   * the exchange buffer is double-buffered by iteration parity (a fast block may be one matvec ahead of a slow
+//     block that still reads the previous product);
+//   * every barrier wait is bounded (the kernel drains with status -2 instead of hanging if the blocks cannot all be
+//     resident - they are: at most one block per CU is launched);
+//   * block 0 writes w, every block its rows of G w (the rho prediction of the single-sweep iteration wants it), and
+//     (done, iterations) go to pinned host memory: one host wait per w-step.
+// rows of d <= 2048 (8 elements per thread); wider problems keep the batched path.
+constexpr int WP_THREADS = 256;
+constexpr int WP_PER = 8;
+constexpr int WP_BAR_STRIDE = 32;                  // one 128-byte line per counter
+constexpr int WP_BAR_SET = 10 * WP_BAR_STRIDE;     // 8 group counters | top | abort
+constexpr unsigned WP_SPIN_CAP = 1u << 24;
+
+struct WpBarrier {
+    unsigned* set;
+    unsigned ngroups, gsize, epoch;
+};
+
+__device__ inline WpBarrier wp_barrier_init(unsigned* bar, int parity) {
+    WpBarrier b;
+    b.set = bar + parity * WP_BAR_SET;
+    // the other set was used by the previous launch, which has completed: make it ready for the next one
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < WP_BAR_SET; i += WP_THREADS) bar[(parity ^ 1) * WP_BAR_SET + i] = 0u;
+    b.ngroups = gridDim.x < 8u ? gridDim.x : 8u;
+    const unsigned g = blockIdx.x % b.ngroups;
+    b.gsize = (gridDim.x - g + b.ngroups - 1) / b.ngroups;
+    b.epoch = 0;
+    return b;
+}
+
+// device-wide barrier; false = some block gave up waiting (all blocks then return false and the kernel drains)
+__device__ inline bool wp_sync(WpBarrier& b, int* lds_flag) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ++b.epoch;
+        __threadfence();                            // release: this block's rows of the product
+        const unsigned g = blockIdx.x % b.ngroups;
+        const unsigned old = atomicAdd(b.set + g * WP_BAR_STRIDE, 1u);
+        if (old + 1 == b.epoch * b.gsize) atomicAdd(b.set + 8 * WP_BAR_STRIDE, 1u);
+        const unsigned want = b.epoch * b.ngroups;
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(b.set + 8 * WP_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            if (++spins > WP_SPIN_CAP ||
+                __hip_atomic_load(b.set + 9 * WP_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(b.set + 9 * WP_BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *lds_flag = ok;
+    }
+    __syncthreads();
+    __threadfence();                                // acquire, on every wave: the other blocks' rows
+    return *lds_flag != 0;
+}
+
+// rows [r0, r1) of y = alpha G x + beta x; x in LDS, the block's rows of G in LDS (GLDS) or in global memory
+template <bool GLDS>
+__device__ inline void wp_matvec(const double* __restrict__ G, const double* gs, int ld, int r0, int r1,
+                                 const double* xs, double alpha, double beta, double* __restrict__ y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = r0 + wave; row < r1; row += WP_THREADS / 64) {
+        const double* g = GLDS ? gs + (size_t)(row - r0) * ld : G + (size_t)row * ld;
+        double acc = 0.0;
+        for (int j = lane; j < ld; j += 64) acc = __builtin_fma(g[j], xs[j], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) y[row] = alpha * acc + beta * xs[row];
+    }
+}
+
+template <bool GLDS>
+__device__ inline void wp_stage_rows(const double* __restrict__ G, double* gs, int ld, int r0, int r1) {
+    if (!GLDS) return;
+    const int cnt = (r1 - r0) * ld;
+    const double* src = G + (size_t)r0 * ld;
+    for (int i = threadIdx.x; i < cnt; i += WP_THREADS) gs[i] = src[i];
+}
+
+__device__ inline void wp_publish(int* pin, int done, int iters) {
+    pin[1] = iters;
+    __threadfence_system();
+    *reinterpret_cast<volatile int*>(pin) = done;
+}
+
+// (rho G + reg I) w = rho q by CG, warm-started from w (w_LBFGS.py:31-53 solves the same system by L-BFGS-B)
+template <bool GLDS, int PER>
+__global__ __launch_bounds__(WP_THREADS) void k_cg_persist(const double* __restrict__ G, int ld, int rpb,
+                                                            const double* __restrict__ q, double rho, double reg,
+                                                            double tol, int max_iter, double* __restrict__ w,
+                                                            double* x0, double* x1, double* __restrict__ Gw_out,
+                                                            unsigned* bar, int parity, int* pin) {
+    extern __shared__ double wp_lds[];
+    double* xs = wp_lds;                       // ld
+    double* red = wp_lds + ld;                 // 16 (block sums)
+    int* flag = reinterpret_cast<int*>(red + 16);
+    double* gs = red + 32;                     // rpb * ld
+    const int r0 = blockIdx.x * rpb, r1 = min(ld, r0 + rpb);
+    WpBarrier b = wp_barrier_init(bar, parity);
+    wp_stage_rows<GLDS>(G, gs, ld, r0, r1);
+    double wj[PER], rj[PER], pj[PER], aj[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int j = k * WP_THREADS + threadIdx.x;
+        wj[k] = (j < ld) ? w[j] : 0.0;
+        if (j < ld) xs[j] = wj[k];
+    }
+    __syncthreads();
+    wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, rho, reg, x0);          // A w
+    int iters = 0, done = 0, ok = 1;
+    double rr = 0.0, thr = 0.0;
+    if (!wp_sync(b, flag)) ok = 0;
+    if (ok) {
+        double acc[2] = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = k * WP_THREADS + threadIdx.x;
+            rj[k] = pj[k] = 0.0;
+            if (j < ld) {
+                const double bb = rho * q[j];
+                rj[k] = bb - x0[j];
+                pj[k] = rj[k];
+                acc[0] += rj[k] * rj[k];
+                acc[1] += bb * bb;
+            }
+        }
+        rbl::block_sum<2, WP_THREADS>(acc, red);
+        rr = acc[0];
+        thr = tol * tol * acc[1];
+        done = rr <= thr ? 1 : 0;
+    }
+    while (ok && !done && iters < max_iter) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = k * WP_THREADS + threadIdx.x;
+            if (j < ld) xs[j] = pj[k];
+        }
+        __syncthreads();
+        double* xb = (iters & 1) ? x0 : x1;
+        wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, rho, reg, xb);      // A p
+        if (!wp_sync(b, flag)) {
+            ok = 0;
+            break;
+        }
+        double a1[1] = {0.0};
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = k * WP_THREADS + threadIdx.x;
+            aj[k] = (j < ld) ? xb[j] : 0.0;
+            a1[0] += pj[k] * aj[k];
+        }
+        rbl::block_sum<1, WP_THREADS>(a1, red);
+        const double alpha = (a1[0] > 0.0) ? rr / a1[0] : 0.0;
+        double a2[1] = {0.0};
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            wj[k] += alpha * pj[k];
+            rj[k] -= alpha * aj[k];
+            a2[0] += rj[k] * rj[k];
+        }
+        rbl::block_sum<1, WP_THREADS>(a2, red);
+        const double beta = (rr > 0.0) ? a2[0] / rr : 0.0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) pj[k] = rj[k] + beta * pj[k];
+        rr = a2[0];
+        ++iters;
+        done = (rr <= thr || alpha == 0.0) ? 1 : 0;
+    }
+    if (ok && Gw_out) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = k * WP_THREADS + threadIdx.x;
+            if (j < ld) xs[j] = wj[k];
+        }
+        __syncthreads();
+        wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, Gw_out);  // G w of the solution (rho prediction)
+    }
+    if (blockIdx.x == 0) {
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int j = k * WP_THREADS + threadIdx.x;
+                if (j < ld) w[j] = wj[k];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) wp_publish(pin, ok ? done : -2, iters);
+    }
+}
+
+// smoothed-l1 w-step: the preconditioned nonlinear CG of k_ncg_init / k_ncg_update in one launch
+template <bool GLDS, int PER>
+__global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __restrict__ G, int ld, int rpb,
+                                                             const double* __restrict__ q, NcgParams P, int max_iter,
+                                                             double* __restrict__ w, double* x0, double* x1,
+                                                             double* __restrict__ Gw_out, unsigned* bar, int parity,
+                                                             int* pin) {
+    extern __shared__ double wp_lds[];
+    double* xs = wp_lds;
+    double* red = wp_lds + ld;
+    int* flag = reinterpret_cast<int*>(red + 16);
+    double* gs = red + 32;
+    const int r0 = blockIdx.x * rpb, r1 = min(ld, r0 + rpb);
+    WpBarrier b = wp_barrier_init(bar, parity);
+    wp_stage_rows<GLDS>(G, gs, ld, r0, r1);
+    double wj[PER], gwj[PER], pj[PER], sj[PER], gdj[PER], qj[PER], gpj[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int j = k * WP_THREADS + threadIdx.x;
+        wj[k] = (j < ld) ? w[j] : 0.0;
+        qj[k] = (j < ld) ? q[j] : 0.0;
+        gdj[k] = (j < ld) ? G[(size_t)j * ld + j] : 1.0;
+        if (j < ld) xs[j] = wj[k];
+    }
+    __syncthreads();
+    wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, x0);          // G w
+    int iters = 0, done = 0, ok = 1;
+    double gs_old = 0.0, thr = 0.0, stalled = 0.0;
+    if (!wp_sync(b, flag)) ok = 0;
+    if (ok) {
+        double acc[1] = {0.0};
+        double gmax = 0.0, qmax = 0.0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = k * WP_THREADS + threadIdx.x;
+            gwj[k] = sj[k] = pj[k] = 0.0;
+            if (j < ld) {
+                gwj[k] = x0[j];
+                const double g = P.rho * (gwj[k] - qj[k]) + hub_g(wj[k], P.reg, P.t);
+                sj[k] = precond_inv(P.rho, gdj[k], hub_c(wj[k], P.reg, P.t)) * g;
+                pj[k] = -sj[k];
+                acc[0] += g * sj[k];
+                gmax = fmax(gmax, fabs(g));
+                qmax = fmax(qmax, P.rho * fabs(qj[k]));
+            }
+        }
+        rbl::block_sum<1, WP_THREADS>(acc, red);
+        gmax = block_max1<WP_THREADS>(gmax, red);
+        qmax = block_max1<WP_THREADS>(qmax, red);
+        gs_old = acc[0];
+        thr = P.tol * fmax(qmax, 0.5 * P.reg);
+        done = gmax <= thr ? 1 : 0;
+    }
+    while (ok && !done && iters < max_iter) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = k * WP_THREADS + threadIdx.x;
+            if (j < ld) xs[j] = pj[k];
+        }
+        __syncthreads();
+        double* xb = (iters & 1) ? x0 : x1;
+        wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, xb);      // G p
+        if (!wp_sync(b, flag)) {
+            ok = 0;
+            break;
+        }
+        // exact line search: phi'(a) = a0 + a a1 + sum_j h'(w_j + a p_j) p_j, piecewise linear and increasing
+        double a3[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = k * WP_THREADS + threadIdx.x;
+            gpj[k] = (j < ld) ? xb[j] : 0.0;
+            const double lin = P.rho * (gwj[k] - qj[k]);
+            a3[0] += lin * pj[k];
+            a3[1] += pj[k] * gpj[k];
+            a3[2] += fabs(lin * pj[k]) + fabs(hub_g(wj[k], P.reg, P.t) * pj[k]);
+        }
+        rbl::block_sum<3, WP_THREADS>(a3, red);
+        const double a0 = a3[0], a1 = P.rho * a3[1], ftol = 4e-16 * a3[2];
+        double alpha = 0.0, lo = 0.0, hi = -1.0;
+        for (int it = 0; it < 100; ++it) {
+            double e2[2] = {0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const double u = wj[k] + alpha * pj[k];
+                e2[0] += hub_g(u, P.reg, P.t) * pj[k];
+                e2[1] += hub_c(u, P.reg, P.t) * pj[k] * pj[k];
+            }
+            rbl::block_sum<2, WP_THREADS>(e2, red);
+            const double f = a0 + alpha * a1 + e2[0], slope = a1 + e2[1];
+            if (it == 0 && !(f < 0.0)) break;
+            if (fabs(f) <= ftol) break;
+            if (f < 0.0) lo = alpha; else hi = alpha;
+            double an = (slope > 0.0) ? alpha - f / slope : -1.0;
+            if (hi >= 0.0) {
+                if (!(an > lo && an < hi)) an = 0.5 * (lo + hi);
+            } else if (!(an > lo)) {
+                an = lo > 0.0 ? 2.0 * lo : 1.0;
+            }
+            if (an == alpha) break;
+            alpha = an;
+        }
+        double b3[3] = {0.0, 0.0, 0.0};
+        double gmax = 0.0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = k * WP_THREADS + threadIdx.x;
+            if (j < ld) {
+                wj[k] += alpha * pj[k];
+                gwj[k] += alpha * gpj[k];
+                const double g = P.rho * (gwj[k] - qj[k]) + hub_g(wj[k], P.reg, P.t);
+                const double sn = precond_inv(P.rho, gdj[k], hub_c(wj[k], P.reg, P.t)) * g;
+                b3[0] += g * sn;
+                b3[1] += g * sj[k];
+                b3[2] += g * pj[k];
+                sj[k] = sn;
+                gmax = fmax(gmax, fabs(g));
+            }
+        }
+        rbl::block_sum<3, WP_THREADS>(b3, red);
+        gmax = block_max1<WP_THREADS>(gmax, red);
+        double beta = (gs_old > 0.0) ? fmax(0.0, (b3[0] - b3[1]) / gs_old) : 0.0;
+        if (alpha == 0.0 || -b3[0] + beta * b3[2] >= 0.0) beta = 0.0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) pj[k] = -sj[k] + beta * pj[k];
+        gs_old = b3[0];
+        ++iters;
+        done = (gmax <= thr || (alpha == 0.0 && stalled != 0.0)) ? 1 : 0;
+        stalled = (alpha == 0.0) ? 1.0 : 0.0;
+    }
+    if (ok && Gw_out) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = k * WP_THREADS + threadIdx.x;
+            if (j < ld) xs[j] = wj[k];
+        }
+        __syncthreads();
+        wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, Gw_out);
+    }
+    if (blockIdx.x == 0) {
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int j = k * WP_THREADS + threadIdx.x;
+                if (j < ld) w[j] = wj[k];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) wp_publish(pin, ok ? done : -2, iters);
+    }
+}
+
+struct WpPlan {
+    bool ok, glds;
+    int rpb, nblocks;
+    size_t lds_bytes;
+};
+
+// launch shape of the persistent w-step: rows per block, G rows in LDS when they fit
+WpPlan wp_plan(int64_t ld) {
+    WpPlan p{false, false, 0, 0, 0};
+    static const int enabled = [] {
+        const char* e = getenv("RBL_WSTEP_PERSIST");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    static const int rpb_env = [] {
+        const char* e = getenv("RBL_WPERSIST_RPB");
+        return e ? atoi(e) : 0;
+    }();
+    if (!enabled || ld > (int64_t)WP_THREADS * WP_PER || ld < 4) return p;
+    static const int cus = [] {
+        int dev = 0, c = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+        return c < 1 ? 1 : c;
+    }();
+    int rpb = rpb_env > 0 ? rpb_env : 16;
+    // at most one block per CU: all blocks resident at once (the device-wide barrier needs that)
+    while ((ld + rpb - 1) / rpb > cus) rpb *= 2;
+    const size_t fixed = sizeof(double) * ((size_t)ld + 32);
+    const size_t rows = sizeof(double) * (size_t)rpb * (size_t)ld;
+    p.glds = fixed + rows <= 150 * 1024;
+    if (!p.glds && rpb_env <= 0) {
+        // G rows do not fit: fewer rows per block if that keeps one block per CU
+        int r2 = rpb;
+        while (r2 > 1 && fixed + sizeof(double) * (size_t)r2 * ld > 150 * 1024) r2 /= 2;
+        if ((ld + r2 - 1) / r2 <= cus && fixed + sizeof(double) * (size_t)r2 * ld <= 150 * 1024) {
+            rpb = r2;
+            p.glds = true;
+        }
+    }
+    p.rpb = rpb;
+    p.nblocks = (int)((ld + rpb - 1) / rpb);
+    p.lds_bytes = fixed + (p.glds ? sizeof(double) * (size_t)rpb * ld : 0);
+    p.ok = true;
+    return p;
+}
+
+template <typename K>
+int wp_set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        RBL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return RBL_OK;
+}
+
+// returns RBL_OK with *status = 1 converged / 0 iteration cap / -1 launch failure / -2 barrier gave up
+int run_cg_persist(const WpPlan& pl, const double* G, int64_t ld, const double* q, double rho, double reg, double tol,
+                   int max_iter, double* w, WstepWorkspace& ws, bool want_Gw, int* status, int* iters, hipStream_t s) {
+    int* pin = ws.pin + 4;
+    pin[0] = -1;
+    const int parity = ws.bar_parity;
+    ws.bar_parity ^= 1;
+    double* gw = want_Gw ? ws.Gy : nullptr;
+#define RBL_CG_PERSIST(GL, PR)                                                                                           \
+    do {                                                                                                                 \
+        static size_t lds_set = 0; /* (one attribute call per instantiation and size, not per launch) */                 \
+        if (lds_set < pl.lds_bytes) {                                                                                    \
+            RBL_TRY(wp_set_lds(k_cg_persist<GL, PR>, pl.lds_bytes));                                                     \
+            lds_set = pl.lds_bytes;                                                                                      \
+        }                                                                                                                \
+        hipLaunchKernelGGL((k_cg_persist<GL, PR>), dim3(pl.nblocks), dim3(WP_THREADS), pl.lds_bytes, s, G, (int)ld, pl.rpb, q, \
+                           rho, reg, tol, max_iter, w, ws.r, ws.p, gw, ws.bar, parity, pin);                             \
+    } while (0)
+    const bool narrow = ld <= 4 * WP_THREADS;
+    if (pl.glds && narrow) RBL_CG_PERSIST(true, 4);
+    else if (pl.glds) RBL_CG_PERSIST(true, 8);
+    else if (narrow) RBL_CG_PERSIST(false, 4);
+    else RBL_CG_PERSIST(false, 8);
+#undef RBL_CG_PERSIST
+    RBL_HIP(hipGetLastError());
+    rbl_spin_wait(pin, -1, s);
+    const volatile int* st = pin;
+    *status = st[0];
+    *iters = st[1];
+    return RBL_OK;
+}
+
+int run_ncg_persist(const WpPlan& pl, const double* G, int64_t ld, const double* q, NcgParams P, int max_iter, double* w,
+                    WstepWorkspace& ws, bool want_Gw, int* status, int* iters, hipStream_t s) {
+    int* pin = ws.pin + 8;
+    pin[0] = -1;
+    const int parity = ws.bar_parity;
+    ws.bar_parity ^= 1;
+    double* gw = want_Gw ? ws.Gy : nullptr;
+#define RBL_NCG_PERSIST(GL, PR)                                                                                          \
+    do {                                                                                                                 \
+        static size_t lds_set = 0;                                                                                       \
+        if (lds_set < pl.lds_bytes) {                                                                                    \
+            RBL_TRY(wp_set_lds(k_ncg_persist<GL, PR>, pl.lds_bytes));                                                    \
+            lds_set = pl.lds_bytes;                                                                                      \
+        }                                                                                                                \
+        hipLaunchKernelGGL((k_ncg_persist<GL, PR>), dim3(pl.nblocks), dim3(WP_THREADS), pl.lds_bytes, s, G, (int)ld, pl.rpb, q, \
+                           P, max_iter, w, ws.r, ws.p, gw, ws.bar, parity, pin);                                         \
+    } while (0)
+    const bool narrow = ld <= 4 * WP_THREADS;
+    if (pl.glds && narrow) RBL_NCG_PERSIST(true, 4);
+    else if (pl.glds) RBL_NCG_PERSIST(true, 8);
+    else if (narrow) RBL_NCG_PERSIST(false, 4);
+    else RBL_NCG_PERSIST(false, 8);
+#undef RBL_NCG_PERSIST
+    RBL_HIP(hipGetLastError());
+    rbl_spin_wait(pin, -1, s);
+    const volatile int* st = pin;
+    *status = st[0];
+    *iters = st[1];
+    return RBL_OK;
+}
+
+bool ncg_persist_try(const double* G, int64_t ld, const double* q, NcgParams P, int max_iter, double* w,
+                     WstepWorkspace& ws, bool want_Gw, int* status, int* iters, hipStream_t s, int* rc) {
+    const WpPlan pl = wp_plan(ld);
+    if (!pl.ok || !ws.bar) return false;
+    *rc = run_ncg_persist(pl, G, ld, q, P, max_iter, w, ws, want_Gw, status, iters, s);
+    return true;
+}
+
+}  // namespace
+
 int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rho, double reg, double smooth_t,
               double L, double tol, int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s,
               bool* fs_pending, const double* rho_dev, double* w_prev_out, bool want_Gw) {
     if (fs_pending) *fs_pending = false;
+    ws.gw_valid = false;
     if (ld > (long long)UPD_THREADS * UPD_PER) {
         rbl_set_error("w-step: d=%lld exceeds the single-block update limit %d", (long long)ld, UPD_THREADS * UPD_PER);
         return RBL_ERR_INVALID;
@@ -580,6 +1092,21 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
         return launch_ridge_eig(G, ws.eig_Vt, ws.eig_V, ws.eig_lambda, ld, q, rho, reg, w, ws.Gy, ws.r, s);
     }
     if (wstep == RBL_WSTEP_L2) {
+        const WpPlan pl = wp_plan(ld);
+        if (pl.ok && ws.bar) {
+            // the whole CG in one persistent launch (k_cg_persist)
+            int status = 0, it = 0;
+            RBL_TRY(run_cg_persist(pl, G, ld, q, rho, reg, tol, max_inner < 20000 ? max_inner : 20000, w, ws, want_Gw, &status,
+                                   &it, s));
+            if (status < 0) {
+                rbl_set_error("w-step: the persistent CG kernel did not complete (status %d)", status);
+                return RBL_ERR_HIP;
+            }
+            if (status == 1) ws.last_iters = it;
+            ws.gw_valid = want_Gw;
+            if (iters_host) *iters_host = it;
+            return RBL_OK;
+        }
         // (rho G + reg I) w = rho q.  The warm-started CG needs about as many iterations as last
         // time: one batch of that many (+2) is enqueued, its last update publishes (done,
         // iterations) to pinned memory and the host spins on that word - one host round trip per
@@ -631,7 +1158,7 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
         return e && e[0] == '1';
     }();
     if (smooth_fista) return run_fista(1, G, ld, q, rho, reg, smooth_t, L, tol, max_inner, w, ws, iters_host, s);
-    return run_ncg(G, ld, q, rho, reg, smooth_t, L, tol, max_inner, w, ws, iters_host, s);
+    return run_ncg(G, ld, q, rho, reg, smooth_t, L, tol, max_inner, w, ws, iters_host, s, want_Gw);
 }
 
 int finish_wstep_l1(const double* G, int64_t ld, const double* q, double rho, double reg, double L, double tol,

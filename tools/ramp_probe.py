@@ -34,28 +34,25 @@ sys.path.insert(0, ROOT)
 
 
 class Sampler(threading.Thread):
-    def __init__(self, period=0.002):
+    """samples EVERY amdgpu card of the host (the box shows all of them in sysfs, one is ours): the card whose
+    gpu_busy_percent moves during the run is the one the probe ran on"""
+    KEYS = ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk", "gpu_busy_percent")
+
+    def __init__(self, period=0.004):
         super().__init__(daemon=True)
         self.period = period
         self.stop = False
         self.rows = []
-        dev = None
+        self.cards = {}
         for c in sorted(glob.glob("/sys/class/drm/card*/device")):
-            if os.path.exists(os.path.join(c, "pp_dpm_sclk")):
-                dev = c
-                break
-        self.files = {}
-        if dev:
-            for k in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk", "pp_dpm_socclk", "gpu_busy_percent", "mem_busy_percent"):
-                p = os.path.join(dev, k)
-                if os.access(p, os.R_OK):
-                    self.files[k] = p
-            for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
-                for k in ("power1_average", "power1_input", "freq1_input", "freq2_input"):
-                    p = os.path.join(hw, k)
-                    if os.access(p, os.R_OK):
-                        self.files[k] = p
-        self.dev = dev
+            if not os.path.exists(os.path.join(c, "pp_dpm_sclk")):
+                continue
+            files = {k: os.path.join(c, k) for k in self.KEYS if os.access(os.path.join(c, k), os.R_OK)}
+            for hw in glob.glob(os.path.join(c, "hwmon", "hwmon*")):
+                for k in ("power1_average", "power1_input"):
+                    if os.access(os.path.join(hw, k), os.R_OK):
+                        files["power"] = os.path.join(hw, k)
+            self.cards[c.split("/")[-2]] = files
 
     @staticmethod
     def _active(txt):
@@ -66,15 +63,15 @@ class Sampler(threading.Thread):
 
     def run(self):
         while not self.stop:
-            t = time.perf_counter()
-            row = {"t": t}
-            for k, p in self.files.items():
-                try:
-                    with open(p) as f:
-                        txt = f.read()
-                    row[k] = self._active(txt) if k.startswith("pp_dpm") else txt.strip()
-                except OSError:
-                    pass
+            row = {"t": time.perf_counter()}
+            for card, files in self.cards.items():
+                for k, p in files.items():
+                    try:
+                        with open(p) as f:
+                            txt = f.read()
+                        row[card + ":" + k] = self._active(txt) if k.startswith("pp_dpm") else txt.strip()
+                    except OSError:
+                        pass
             self.rows.append(row)
             time.sleep(self.period)
 
@@ -117,7 +114,7 @@ def main():
         torch.cuda.synchronize()
         return [float(x) for x in s.kernel_samples(_lib.KERNEL_SWEEP_ERM)], t
 
-    out = {"rows": a.rows, "cols": a.cols, "sections": [], "sysfs_device": smp.dev, "sysfs_files": sorted(smp.files)}
+    out = {"rows": a.rows, "cols": a.cols, "sections": []}
     mark("A")
     ms, t = run_iters(60)
     out["sections"].append({"name": "A: 60 iterations right after set-up", "kernel_ms": ms})
@@ -139,19 +136,23 @@ def main():
     mark("end")
     smp.stop = True
     smp.join(1.0)
-    # clock samples: collapse to change points per section
+    # the card(s) that were busy at some point = ours; per section the range of each reported clock / power
     t0 = marks[0][1]
-    changes = []
-    prev = None
-    for r in smp.rows:
-        key = tuple((k, r.get(k)) for k in sorted(r) if k not in ("t", "power1_average", "power1_input", "gpu_busy_percent", "mem_busy_percent"))
-        if key != prev:
-            changes.append(dict(r, t=round((r["t"] - t0) * 1e3, 2)))
-            prev = key
+    busy_cards = sorted({k.split(":")[0] for r in smp.rows for k, v in r.items() if k.endswith("gpu_busy_percent") and v not in ("0", "")})
+    out["cards_seen"] = sorted(smp.cards)
+    out["cards_busy_during_run"] = busy_cards
     out["marks_ms"] = [(n, round((t - t0) * 1e3, 2)) for n, t in marks]
-    out["clock_changes"] = changes[:4000]
-    pw = [(round((r["t"] - t0) * 1e3, 1), r.get("power1_average") or r.get("power1_input")) for r in smp.rows[::25]]
-    out["power_samples"] = pw[:4000]
+    sect = []
+    for i in range(len(marks) - 1):
+        lo, hi = marks[i][1], marks[i + 1][1]
+        rows = [r for r in smp.rows if lo <= r["t"] < hi]
+        summ = {"section": marks[i][0], "samples": len(rows)}
+        for card in (busy_cards or sorted(smp.cards)[:1]):
+            for k in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk", "gpu_busy_percent", "power"):
+                vals = sorted({r.get(card + ":" + k) for r in rows if r.get(card + ":" + k) is not None})
+                summ[card + ":" + k] = vals if len(vals) <= 6 else [vals[0], "...", vals[-1], "%d distinct" % len(vals)]
+        sect.append(summ)
+    out["clock_summary_per_section"] = sect
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(out, f)
@@ -159,9 +160,9 @@ def main():
         k = sec["kernel_ms"]
         print("%-66s first %.3f  2nd %.3f  5th %.3f  10th %.3f  20th %.3f  last %.3f  min %.3f" % (
             sec["name"], k[0], k[1], k[4], k[9], k[19], k[-1], min(k)), file=sys.stderr)
-    print("sysfs:", smp.dev, sorted(smp.files), "clock change points:", len(changes), file=sys.stderr)
-    for c in changes[:60]:
-        print(c, file=sys.stderr)
+    print("cards in sysfs:", sorted(smp.cards), " busy during the run:", busy_cards, file=sys.stderr)
+    for sm in sect:
+        print(json.dumps(sm), file=sys.stderr)
     s.close()
     filler.close()
 
