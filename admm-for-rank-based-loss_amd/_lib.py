@@ -107,7 +107,8 @@ SIGNATURES = {
     "rbl_zbd_hist": (C.c_int, [_P, C.c_int]),
     "rbl_zbd_scan": (C.c_int, [_P, C.c_int]),
     "rbl_zbd_eval": (C.c_int, [_P, C.c_int]),
-    "rbl_zbd_decide": (C.c_int, [_P, C.c_int, C.c_int]),
+    "rbl_zbd_decide": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "rbl_zbd_root_passes": (C.c_int, []),
     "rbl_zbd_gather": (C.c_int, [_P, C.c_int]),
     "rbl_zbd_finish": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_int]),
     "rbl_zbd_apply": (C.c_int, [_P, C.POINTER(C.c_int)]),

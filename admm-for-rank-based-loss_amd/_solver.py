@@ -330,8 +330,17 @@ class Solver:
     def zbd_eval(self, k):
         _lib.check(self.lib.rbl_zbd_eval(self._h, int(k)))
 
-    def zbd_decide(self, k, last):
-        _lib.check(self.lib.rbl_zbd_decide(self._h, int(k), int(bool(last))))
+    def zbd_decide(self, k, last, want_settled=True):
+        """-> settled (bool; the same on every rank) when want_settled, else None (no host wait)"""
+        if not want_settled:
+            _lib.check(self.lib.rbl_zbd_decide(self._h, int(k), int(bool(last)), None))
+            return None
+        st = C.c_int(0)
+        _lib.check(self.lib.rbl_zbd_decide(self._h, int(k), int(bool(last)), C.byref(st)))
+        return bool(st.value)
+
+    def zbd_root_passes(self):
+        return int(self.lib.rbl_zbd_root_passes())
 
     def zbd_gather(self, k):
         _lib.check(self.lib.rbl_zbd_gather(self._h, int(k)))

@@ -115,7 +115,7 @@ struct rbl_solver {
         double* tot = nullptr;     // multi-GPU: the sums of one root pass (all-reduced by the driver)
         double* pack = nullptr;    // multi-GPU: [count | undecided elements] of this rank (all-gathered by the driver)
         int* pin = nullptr;    // pinned: [0] sequence number (written last), [1] status
-        int seq = 0, mode = 0;
+        int seq = 0, mode = 0, dseq = 0;
         int64_t backoff = 0, skip_until = 0;   // after an uncertified z-step the fast path pauses for 2, 4, ... 64 iterations   // mode of the iteration in flight: 0 sort, 1 banded, 2 banded then redone with the sort
     } zb;
 };
@@ -460,7 +460,7 @@ int zb_setup(rbl_solver* h) {
     RBL_TRY(dev_alloc(&h->zb.tot, (size_t)(4 * ZB_C)));
     RBL_TRY(dev_alloc(&h->zb.pack, (size_t)(ZB_GCAP + 1)));
     RBL_HIP(hipHostMalloc((void**)&h->zb.pin, 64, hipHostMallocDefault));
-    h->zb.pin[0] = h->zb.pin[1] = 0;
+    for (int i = 0; i < 16; ++i) h->zb.pin[i] = 0;
     h->zb.enabled = true;
     return RBL_OK;
 }
@@ -1881,11 +1881,27 @@ int rbl_zbd_eval(rbl_solver* h, int k) {
     RBL_TRY(zbd_ready(h));
     return launch_zbd_eval(h->cfg.loss, h->zb.cfg, h->n, h->sw.keys[0], h->zb.st, k, h->step_rho, h->zb.part, h->zb.tot, h->stream);
 }
-int rbl_zbd_decide(rbl_solver* h, int k, int last) {
+int rbl_zbd_decide(rbl_solver* h, int k, int last, int* settled) {
     RBL_ENTER_ITER(h);
     RBL_TRY(zbd_ready(h));
-    return launch_zbd_decide(h->cfg.loss, h->zb.cfg, h->zb.st, k, h->step_rho, h->zb.tot, last, h->stream);
+    if (!settled) return launch_zbd_decide(h->cfg.loss, h->zb.cfg, h->zb.st, k, h->step_rho, h->zb.tot, last, h->stream);
+    // the verdict of this pass through pinned memory (one host wait): every rank reads the same answer, the driver stops
+    // issuing root passes (and their all-reduces) for this cluster after the pass that settles it
+    volatile int* pin = h->zb.pin + 4;
+    h->zb.dseq = (h->zb.dseq & 0x3fffffff) + 1;
+    pin[0] = 0;
+    RBL_TRY(launch_zbd_decide(h->cfg.loss, h->zb.cfg, h->zb.st, k, h->step_rho, h->zb.tot, last, h->stream, h->zb.pin + 4,
+                              h->zb.dseq));
+    rbl_spin_wait(pin, 0, h->stream);
+    if (pin[0] != h->zb.dseq) {
+        rbl_set_error("zbd_decide: the verdict of the root pass was never written");
+        (void)hipGetLastError();
+        return RBL_ERR_HIP;
+    }
+    *settled = pin[1];
+    return RBL_OK;
 }
+int rbl_zbd_root_passes(void) { return ZB_ROOT_PASSES; }
 int rbl_zbd_gather(rbl_solver* h, int k) {
     RBL_ENTER_ITER(h);
     RBL_TRY(zbd_ready(h));

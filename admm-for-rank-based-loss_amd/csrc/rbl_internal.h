@@ -315,7 +315,8 @@ int launch_zbd_hist(int64_t n, const u64* keys, ZbState* st, u32* hist, int pass
 int launch_zbd_scan(int loss, const ZbConfig& cfg, ZbState* st, u32* hist, int pass, double rho, hipStream_t s);
 int launch_zbd_eval(int loss, const ZbConfig& cfg, int64_t n, const u64* keys, ZbState* st, int k, double rho, double* partials,
                     double* tot, hipStream_t s);
-int launch_zbd_decide(int loss, const ZbConfig& cfg, ZbState* st, int k, double rho, const double* tot, int last, hipStream_t s);
+int launch_zbd_decide(int loss, const ZbConfig& cfg, ZbState* st, int k, double rho, const double* tot, int last, hipStream_t s,
+                      int* pin_settled = nullptr, int dseq = 0);
 int launch_zbd_gather(int loss, const ZbConfig& cfg, int64_t n, const u64* keys, ZbState* st, int k, double rho, double* partials,
                       double* pack, hipStream_t s);
 int launch_zbd_finish(int loss, const ZbConfig& cfg, ZbState* st, int k, double rho, double* partials, const double* packs_all,

@@ -505,44 +505,9 @@ __global__ __launch_bounds__(ZB_THREADS) void k_zb_eval(const u64* __restrict__ 
     }
 }
 
-// one block: sums over the eval blocks, psi at the candidates, the next bracket or the block value
+// psi at the candidates of one root pass (tot: the summed block sums), the next bracket or the block value - one thread
 template <int LOSS>
-// Across GPUs the two halves run as separate launches with an all-reduce in between: tot_out != NULL stops after the
-// local sums (written there, zeros when this cluster is settled), tot_in != NULL starts from the summed totals.
-__global__ __launch_bounds__(1024) void k_zb_refine(ZbState* __restrict__ st, ZbConfig cfg, int k, double rho,
-                                                     const double* __restrict__ partials, int nblocks, int last,
-                                                     double* __restrict__ tot_out, const double* __restrict__ tot_in) {
-    const bool idle = st->status != ZB_OK || st->done[k] || st->und[k] <= (double)ZB_GCAP;
-    if (idle) {
-        if (tot_out && threadIdx.x < 4 * ZB_C) tot_out[threadIdx.x] = 0.0;
-        return;
-    }
-    __shared__ double tot[4 * ZB_C];
-    if (tot_in) {
-        if (threadIdx.x < 4 * ZB_C) tot[threadIdx.x] = tot_in[threadIdx.x];
-        __syncthreads();
-    } else {
-        // 16 threads per value (coalesced over the 64 values): thread (v, part) sums blocks part, part + 16, ... in
-        // order, then the 16 partial sums in order
-        const int v = threadIdx.x & 63, part = threadIdx.x >> 6;
-        double s = 0.0;
-#pragma unroll 4
-        for (int b = part; b < nblocks; b += 16) s += partials[(size_t)b * 4 * ZB_C + v];
-        __shared__ double tmp[4 * ZB_C * 16];
-        tmp[part * 64 + v] = s;
-        __syncthreads();
-        if (part == 0) {
-            double a = 0.0;
-            for (int p = 0; p < 16; ++p) a += tmp[p * 64 + v];
-            tot[v] = a;
-        }
-        __syncthreads();
-    }
-    if (tot_out) {
-        if (threadIdx.x < 4 * ZB_C) tot_out[threadIdx.x] = tot[threadIdx.x];
-        return;
-    }
-    if (threadIdx.x != 0) return;
+__device__ inline void zb_decide(ZbState* __restrict__ st, const ZbConfig& cfg, int k, double rho, const double* tot, int last) {
     const int L = cfg.cl_L[k], R = cfg.cl_R[k];
     const double* MT = tot;
     const double* NT = tot + ZB_C;
@@ -626,6 +591,61 @@ __global__ __launch_bounds__(1024) void k_zb_refine(ZbState* __restrict__ st, Zb
         }
     }
     if (found) zb_accept<LOSS>(st, cfg, k, rho, x, cT, mT, cB, mB);
+}
+
+// one block: sums over the eval blocks, psi at the candidates, the next bracket or the block value
+template <int LOSS>
+// Across GPUs the two halves run as separate launches with an all-reduce in between: tot_out != NULL stops after the
+// local sums (written there, zeros when this cluster is settled), tot_in != NULL starts from the summed totals.
+__global__ __launch_bounds__(1024) void k_zb_refine(ZbState* __restrict__ st, ZbConfig cfg, int k, double rho,
+                                                     const double* __restrict__ partials, int nblocks, int last,
+                                                     double* __restrict__ tot_out, const double* __restrict__ tot_in,
+                                                     int* pin_settled = nullptr, int dseq = 0) {
+    // pin_settled (multi-GPU driver, pinned host memory): [1] = "this cluster needs no further root pass" (settled, few
+    // enough undecided elements for the gather, or the step has failed), then [0] = dseq.  The state is a function of the
+    // SUMMED totals, so every rank reads the same answer and stops issuing all-reduces after the pass that settles.
+    const bool idle = st->status != ZB_OK || st->done[k] || st->und[k] <= (double)ZB_GCAP;
+    if (idle) {
+        if (tot_out && threadIdx.x < 4 * ZB_C) tot_out[threadIdx.x] = 0.0;
+        if (pin_settled && threadIdx.x == 0) {
+            pin_settled[1] = 1;
+            __threadfence_system();
+            *reinterpret_cast<volatile int*>(pin_settled) = dseq;
+        }
+        return;
+    }
+    __shared__ double tot[4 * ZB_C];
+    if (tot_in) {
+        if (threadIdx.x < 4 * ZB_C) tot[threadIdx.x] = tot_in[threadIdx.x];
+        __syncthreads();
+    } else {
+        // 16 threads per value (coalesced over the 64 values): thread (v, part) sums blocks part, part + 16, ... in
+        // order, then the 16 partial sums in order
+        const int v = threadIdx.x & 63, part = threadIdx.x >> 6;
+        double s = 0.0;
+#pragma unroll 4
+        for (int b = part; b < nblocks; b += 16) s += partials[(size_t)b * 4 * ZB_C + v];
+        __shared__ double tmp[4 * ZB_C * 16];
+        tmp[part * 64 + v] = s;
+        __syncthreads();
+        if (part == 0) {
+            double a = 0.0;
+            for (int p = 0; p < 16; ++p) a += tmp[p * 64 + v];
+            tot[v] = a;
+        }
+        __syncthreads();
+    }
+    if (tot_out) {
+        if (threadIdx.x < 4 * ZB_C) tot_out[threadIdx.x] = tot[threadIdx.x];
+        return;
+    }
+    if (threadIdx.x != 0) return;
+    zb_decide<LOSS>(st, cfg, k, rho, tot, last);
+    if (pin_settled) {
+        pin_settled[1] = (st->status != ZB_OK || st->done[k] || st->und[k] <= (double)ZB_GCAP) ? 1 : 0;
+        __threadfence_system();
+        *reinterpret_cast<volatile int*>(pin_settled) = dseq;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ gather + finish
@@ -1159,13 +1179,14 @@ int launch_zbd_eval(int loss, const ZbConfig& cfg, int64_t n, const u64* keys, Z
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }
-int launch_zbd_decide(int loss, const ZbConfig& cfg, ZbState* st, int k, double rho, const double* tot, int last, hipStream_t s) {
+int launch_zbd_decide(int loss, const ZbConfig& cfg, ZbState* st, int k, double rho, const double* tot, int last, hipStream_t s,
+                      int* pin_settled, int dseq) {
     if (loss == RBL_LOSS_BCE)
         hipLaunchKernelGGL(k_zb_refine<0>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)nullptr, 0, last,
-                           (double*)nullptr, tot);
+                           (double*)nullptr, tot, pin_settled, dseq);
     else
         hipLaunchKernelGGL(k_zb_refine<1>, dim3(1), dim3(1024), 0, s, st, cfg, k, rho, (const double*)nullptr, 0, last,
-                           (double*)nullptr, tot);
+                           (double*)nullptr, tot, pin_settled, dseq);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

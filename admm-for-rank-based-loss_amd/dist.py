@@ -220,7 +220,10 @@ class GpuEngine:
         return self._zdv(_lib.BUF_ZB_TOT, "<f8")
 
     def zbd_decide(self, k, last):
-        self.s.zbd_decide(k, last)
+        return self.s.zbd_decide(k, last)
+
+    def zbd_root_passes(self):
+        return self.s.zbd_root_passes()
 
     def zbd_gather(self, k):
         from . import _lib
@@ -260,6 +263,8 @@ class ShardedADMM:
         self.always_allreduce = False
         self.banded_z = os.environ.get("RBL_NO_ZBAND") != "1"   # sort-free z-step for banded rank weights where it applies
         self.n_coll = 0      # collectives issued in the iteration in flight
+        self.n_coll_z = 0    # ... of which by its z-step
+        self.zb_clusters = 0 # band edges that can pool (sort-free z-step: 6 + 2 collectives per edge in steady state)
         self.n_sync = 0      # host waits of this driver in the iteration in flight (device -> host reads)
 
     def _allreduce(self, t):
@@ -416,11 +421,9 @@ class ShardedADMM:
         self._alltoall(bu, recv_counts, zu, send_counts)
         e.zd_scatter(n_back)
 
-    ZB_ROOT_PASSES = 4   # (csrc/rbl_internal.h)
-
     def _z_banded(self):
         """z-step for rank weights that are constant on a few bands (superquantile, aorr, aorr_dc) WITHOUT a sort:
-        per select pass one sum of a 12 288-bin integer histogram, per root pass one sum of 64 doubles, one gather of
+        per select pass one sum of a 12 288-bin integer histogram, per root pass (one in steady state) one sum of 64 doubles, one gather of
         the <= 2048 undecided elements per band edge that can pool - no sample sort, no all-to-all, no merge tree
         (include/rbl.h: rbl_zbd_*; csrc/zband.hip).  Every rank holds the same state throughout, so every rank reads
         the same verdict: False = not applicable / not certified, the caller runs the sort-based z-step."""
@@ -428,13 +431,20 @@ class ShardedADMM:
         ok, clusters = e.zbd_begin()
         if not ok:
             return False
+        self.zb_clusters = len(clusters)
         for p in range(6):
             self._allreduce(e.zbd_hist(p))
             e.zbd_scan(p)
+        passes = e.zbd_root_passes()             # (the library's constant, through the C ABI)
         for k in clusters:
-            for r in range(self.ZB_ROOT_PASSES):
+            for r in range(passes):
                 self._allreduce(e.zbd_eval(k))
-                e.zbd_decide(k, r == self.ZB_ROOT_PASSES - 1)
+                # the verdict of the pass is a function of the SUMMED totals: every rank reads the same one (one host
+                # wait on a pinned word) and stops after the pass that settles - in steady state the first, its
+                # candidates sit around a prediction from the last block values: 1 all-reduce per edge instead of 4
+                self.n_sync += 1
+                if e.zbd_decide(k, r == passes - 1):
+                    break
             e.zbd_finish(k, self._gather_small(e.zbd_gather(k)), self.world)
         self.n_sync += 1          # the verdict is read on the host
         return e.zbd_apply() == 0
@@ -479,6 +489,7 @@ class ShardedADMM:
             if e.sorted_path and self.world > 1:
                 m_all = self._allgather_rows(e.buf("m"))
             e.phase_z(m_all)
+        self.n_coll_z = self.n_coll
         e.phase_q()
         pending = getattr(e, "pending_reduce", None)
         if pending is None:                       # plain engines: q and the residuals are two buffers
@@ -510,5 +521,5 @@ class ShardedADMM:
                 st.objective += e.risk_from_v(self._allgather_rows(e.buf("v")))
         # how the iteration talked: collectives issued, host waits of this driver (the library's own are
         # st.host_syncs: the statistics block, the w-step's status word)
-        st.collectives, st.driver_syncs = self.n_coll, self.n_sync
+        st.collectives, st.driver_syncs, st.z_collectives = self.n_coll, self.n_sync, self.n_coll_z
         return st

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RBL_VERSION 104
+#define RBL_VERSION 105
 
 /* status codes */
 enum {
@@ -255,7 +255,11 @@ int  rbl_zd_scatter(rbl_solver* h, int64_t n_back);
  *   rbl_zbd_begin     *applicable = 0: not such weights / iteration 0 / pausing after an uncertified step -> rbl_zd_*.
  *                     *root_clusters: bit k set = band edge k can pool.
  *   for pass 0..5:    rbl_zbd_hist(pass); SUM RBL_BUF_ZB_HIST over the ranks; rbl_zbd_scan(pass)
- *   for every set bit k, 4 times:  rbl_zbd_eval(k); SUM RBL_BUF_ZB_TOT; rbl_zbd_decide(k, last = 4th time)
+ *   for every set bit k, up to rbl_zbd_root_passes() times:  rbl_zbd_eval(k); SUM RBL_BUF_ZB_TOT;
+ *                     rbl_zbd_decide(k, last = final time, &settled) - settled != 0 (the same on every rank: the state is
+ *                     a function of the summed totals; one host wait on a pinned word): no further pass for this k.
+ *                     In steady state the first pass settles (its candidates sit around a prediction from the last
+ *                     block values).  settled = NULL: no host wait, the caller issues all passes (spare ones are idle).
  *                     then rbl_zbd_gather(k); ALL-GATHER RBL_BUF_ZB_PACK; rbl_zbd_finish(k, gathered, world)
  *   rbl_zbd_apply     z and c = z + lambda/rho of the local rows; *status = 0: certified (go on with rbl_phase_q),
  *                     otherwise every rank got the same non-zero status: run rbl_zd_* for this iteration.            */
@@ -263,7 +267,8 @@ int  rbl_zbd_begin(rbl_solver* h, int* applicable, int* root_clusters);
 int  rbl_zbd_hist(rbl_solver* h, int pass);
 int  rbl_zbd_scan(rbl_solver* h, int pass);
 int  rbl_zbd_eval(rbl_solver* h, int k);
-int  rbl_zbd_decide(rbl_solver* h, int k, int last);
+int  rbl_zbd_decide(rbl_solver* h, int k, int last, int* settled);
+int  rbl_zbd_root_passes(void);
 int  rbl_zbd_gather(rbl_solver* h, int k);
 int  rbl_zbd_finish(rbl_solver* h, int k, const void* packs_all_dev, int world);
 int  rbl_zbd_apply(rbl_solver* h, int* status);

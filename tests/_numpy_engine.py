@@ -128,6 +128,10 @@ class NumpyEngine:
 
     def zbd_decide(self, k, last):
         self._zb.decide(k, self._zb_tot.numpy(), last)
+        return self._zb._idle(k)         # "settled": what rbl_zbd_decide reports through its pinned word
+
+    def zbd_root_passes(self):
+        return zband.ROOT_PASSES
 
     def zbd_gather(self, k):
         return torch.from_numpy(self._zb.gather(k).copy())

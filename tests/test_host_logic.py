@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # the Python binding covers the same set
     assert declared == set(rbl._lib.SIGNATURES), declared ^ set(rbl._lib.SIGNATURES)
-    assert lib.rbl_version() == 104
+    assert lib.rbl_version() == 105
 
 
 def test_no_cpu_fallback_without_device():
@@ -109,12 +109,14 @@ def _worker(rank, world, port, cfg, out):
         drv = ShardedADMM(eng, dist_z=cfg.get("dist_z", True))
         drv.banded_z = cfg.get("banded", False)      # the sort-free z-step for banded weights only where a case asks for it
         drv.setup_gram()
-        hist = []
+        hist, zcoll = [], []
         for _ in range(cfg["iters"]):
+            nb = getattr(eng, "n_banded", 0)
             st = drv.step(want_objective=True)
             hist.append((st.primal, st.dual, st.rho, st.objective))
+            zcoll.append((st.z_collectives, getattr(eng, "n_banded", 0) - nb, drv.zb_clusters))
         if rank == 0:
-            np.savez(out, w=eng.w, hist=np.array(hist),
+            np.savez(out, w=eng.w, hist=np.array(hist), zcoll=np.array(zcoll),
                      fused=getattr(eng, "n_fused", 0), mispred=getattr(eng, "n_mispred", 0), banded=getattr(eng, "n_banded", 0))
     finally:
         dist.destroy_process_group()
@@ -177,6 +179,14 @@ def test_sort_free_distributed_z_step(world, cfg, tmp_path):
     against the single-process oracle.  The sort-free path must have been certified on all but the first iterations."""
     got = _check_sharded(dict(cfg, banded=True), world, tmp_path)
     assert int(got["banded"]) >= cfg["iters"] - 4, int(got["banded"])
+    # collectives of a certified sort-free z-step: 6 histogram sums + per band edge that can pool ONE root-pass sum (the
+    # ranks stop after the pass that settles: rbl_zbd_decide's verdict) and one gather - 8 for one edge, where round 2
+    # always issued 4 root-pass sums (11).  The first certified steps may need a second pass (no history yet).
+    zc = got["zcoll"]
+    steady = [int(c) for c, banded, _ in zc[-4:] if banded]
+    edges = int(zc[-1][2])
+    assert len(steady) >= 3 and max(steady) <= 6 + 2 * edges, (zc.tolist(), edges)
+    assert all(int(c) <= 6 + 5 * int(e) for c, banded, e in zc if banded), zc.tolist()
 
 
 def _check_sharded(cfg, world, tmp_path):
