@@ -265,6 +265,7 @@ int alloc_wstep(WstepWorkspace& ww, int64_t ld) {
     RBL_TRY(dev_alloc(&ww.flags, 8));
     RBL_TRY(dev_alloc(&ww.bar, (size_t)WSTEP_BAR_UINTS));
     RBL_HIP(hipMemset(ww.bar, 0, sizeof(unsigned) * WSTEP_BAR_UINTS));
+    RBL_TRY(dev_alloc(&ww.xch, (size_t)WSTEP_XCH_DOUBLES));
     RBL_TRY(alloc_wstep_pin(ww));
     return RBL_OK;
 }
@@ -274,6 +275,7 @@ void free_wstep(WstepWorkspace& ww) {
     dev_free(ww.yk); dev_free(ww.Gy); dev_free(ww.wn); dev_free(ww.r); dev_free(ww.p); dev_free(ww.scal);
     dev_free(ww.flags);
     dev_free(ww.bar);
+    dev_free(ww.xch);
     free_wstep_pin(ww);
     ww = WstepWorkspace{};
 }
@@ -2352,7 +2354,8 @@ int rbl_k_wstep(int wstep, int64_t d, const double* G, const double* q, double r
     ww.scal = sc.alloc<double>(8);
     ww.flags = sc.alloc<int>(8);
     ww.bar = sc.alloc<unsigned>((size_t)WSTEP_BAR_UINTS);
-    SC_CHECK(ww.yk && ww.Gy && ww.wn && ww.r && ww.p && ww.scal && ww.flags && ww.bar);
+    ww.xch = sc.alloc<double>((size_t)WSTEP_XCH_DOUBLES);
+    SC_CHECK(ww.yk && ww.Gy && ww.wn && ww.r && ww.p && ww.scal && ww.flags && ww.bar && ww.xch);
     RBL_HIP(hipMemsetAsync(ww.bar, 0, sizeof(unsigned) * WSTEP_BAR_UINTS, sc.s));
     RBL_TRY(alloc_wstep_pin(ww));
     struct PinGuard {

@@ -195,10 +195,13 @@ struct WstepWorkspace {
     // persistent one-launch w-steps (wstep.hip: k_cg_persist / k_ncg_persist): two sets of barrier counters used
     // alternately (a launch clears the set of the next one), pin[4..5] / pin[8..9] = their (status, iterations)
     unsigned* bar;
+    double* xch;    // the two exchange buffers of the matrix-vector products (one 128-byte line per block, double-buffered)
     int bar_parity;
     bool gw_valid;  // ws.Gy holds G w of the w the last run_wstep returned
 };
 constexpr int WSTEP_BAR_UINTS = 2 * 10 * 32;
+constexpr int WSTEP_PERSIST_MAX_LD = 2048;                                  // 8 vector elements per thread of a 256-thread block
+constexpr int WSTEP_XCH_DOUBLES = 2 * (WSTEP_PERSIST_MAX_LD + 16);
 int launch_power_iteration(const double* G, int64_t d, double* tmp1, double* tmp2, double* scal, int iters,
                            double* lambda_host, hipStream_t s);
 // lasso / smoothed-l1 by FISTA with restart, ridge by CG; w is updated in place.

@@ -593,29 +593,41 @@ int run_ncg(const double* G, int64_t ld, const double* q, double rho, double reg
 namespace {
 
 // ============================================================================================
-// One persistent kernel per d-space w-step (round 3).  The batched path above spends ~5 us per launch whatever
-// the kernel does (CG: 2 + 2 k launches, nonlinear CG the same), i.e. 0.15 ms (CG) / 0.2-0.6 ms (NCG) per ADMM
-// iteration at d = 1000 for a few microseconds of arithmetic.  Here the whole w-step is ONE launch:
-//   * block b owns `rpb` consecutive rows of G, staged ONCE into its LDS (16 rows x 1000 doubles = 128 KB): per inner
-//     iteration it computes its rows of G p from LDS and writes them to an exchange buffer;
-//   * ONE device-wide barrier per inner iteration (hierarchical: a counter per group of blocks, then a top counter;
-//     release / acquire fences at agent scope around it), after which every block reads the whole product (8 KB)
-//     and performs the REST of the iteration - dot products, step length, vector updates, the exact line search of
-//     the nonlinear CG - redundantly on vectors it keeps in registers.  Identical arithmetic on identical inputs in a
-//     fixed order: every block holds the same bits, so convergence is decided identically everywhere and no flag has
-//     to be exchanged; standard CG / NCG arithmetic, nothing pipelined or reordered across iterations;
+// One persistent kernel per d-space w-step (round 3).  The batched path above runs 2 + 2 k kernels of ~5 us each
+// with ~1.5 us of boundary between them (CG at d = 1000: ~14 us per inner iteration, 0.10 ms per ADMM iteration; the
+// nonlinear CG 0.2-0.6 ms) for a few microseconds of arithmetic.  Here the whole w-step is ONE launch:
+//   * block b owns `rpb` = 16 consecutive rows of G, staged ONCE into its LDS (16 x 1000 doubles = 128 KB): per inner
+//     iteration it computes its rows of G p from LDS;
+//   * the 16 results leave the block as ONE 128-byte line written by ONE wave instruction of write-through (`sc1`)
+//     8-byte stores, the storing wave drains its stores (s_waitcnt vmcnt(0)) and one lane arrives on a counter
+//     (hierarchical: one counter per group of blocks b % 8 - blocks that share an XCD under the observed placement,
+//     which only matters for speed -, the group's last arriver adds to the top counter); one lane polls the top
+//     counter with `sc1` loads, a workgroup barrier, then every block reads the whole product (8 KB) with 16-byte
+//     `sc1` buffer loads.  No cache is written back or invalidated: every handed-off byte is stored AND loaded `sc1`
+//     (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": the row "agent-scope
+//     atomic adds, one lane of each storing workgroup / sc1 poll / workgroup barrier before every load"); the first
+//     version of this kernel used __threadfence() pairs around the counter and cost as much per inner iteration as
+//     the two launches it replaced (measured: C2l2 242.5 against 243.7 it/s);
+//   * every block then performs the REST of the iteration - dot products, step length, vector updates, the exact line
+//     search of the nonlinear CG - redundantly on vectors it keeps in registers.  Identical arithmetic on identical
+//     inputs in a fixed order: every block holds the same bits, so convergence is decided identically everywhere and
+//     no flag has to be exchanged; standard CG / NCG arithmetic, nothing pipelined or reordered across iterations;
 //   * the exchange buffer is double-buffered by iteration parity (a fast block may be one matvec ahead of a slow
 //     block that still reads the previous product);
-//   * every barrier wait is bounded (the kernel drains with status -2 instead of hanging if the blocks cannot all be
+//   * every wait is bounded (the kernel drains with status -2 instead of hanging if the blocks cannot all be
 //     resident - they are: at most one block per CU is launched);
 //   * block 0 writes w, every block its rows of G w (the rho prediction of the single-sweep iteration wants it), and
 //     (done, iterations) go to pinned host memory: one host wait per w-step.
 // rows of d <= 2048 (8 elements per thread); wider problems keep the batched path.
 constexpr int WP_THREADS = 256;
-constexpr int WP_PER = 8;
+constexpr int WP_RPB = 16;                         // rows of G per block = one 128-byte line of the exchange buffer
 constexpr int WP_BAR_STRIDE = 32;                  // one 128-byte line per counter
 constexpr int WP_BAR_SET = 10 * WP_BAR_STRIDE;     // 8 group counters | top | abort
 constexpr unsigned WP_SPIN_CAP = 1u << 24;
+constexpr int WP_AUX_SC1 = 16;                     // cache-policy bits of a gfx950 buffer access: sc1 (system-coherent, bypasses L1)
+
+typedef unsigned long long wp_u64 __attribute__((address_space(1)));
+typedef unsigned wp_u32 __attribute__((address_space(1)));
 
 struct WpBarrier {
     unsigned* set;
@@ -635,46 +647,74 @@ __device__ inline WpBarrier wp_barrier_init(unsigned* bar, int parity) {
     return b;
 }
 
-// device-wide barrier; false = some block gave up waiting (all blocks then return false and the kernel drains)
-__device__ inline bool wp_sync(WpBarrier& b, int* lds_flag) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        ++b.epoch;
-        __threadfence();                            // release: this block's rows of the product
-        const unsigned g = blockIdx.x % b.ngroups;
-        const unsigned old = atomicAdd(b.set + g * WP_BAR_STRIDE, 1u);
-        if (old + 1 == b.epoch * b.gsize) atomicAdd(b.set + 8 * WP_BAR_STRIDE, 1u);
-        const unsigned want = b.epoch * b.ngroups;
-        unsigned spins = 0;
-        int ok = 1;
-        while (__hip_atomic_load(b.set + 8 * WP_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            if (++spins > WP_SPIN_CAP ||
-                __hip_atomic_load(b.set + 9 * WP_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                __hip_atomic_store(b.set + 9 * WP_BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
+// index of the k-th vector element a thread owns: elements come in pairs (one 16-byte sc1 load each)
+__device__ inline int wp_idx(int k) { return 2 * ((k >> 1) * WP_THREADS + (int)threadIdx.x) + (k & 1); }
+
+// Publishes this block's WP_RPB results (ybuf, LDS) into line blockIdx.x of xb, waits until every block has done so
+// and returns with the whole vector in v[] (the elements this thread owns).  false = some block gave up waiting
+// (every block then returns false and the kernel drains).
+template <int PER>
+__device__ inline bool wp_exchange(WpBarrier& b, const double* ybuf, double* xb, int xbytes, double (&v)[PER], int* lds_flag) {
+    __syncthreads();                                // ybuf complete
+    if (threadIdx.x < 64) {                         // wave 0 stores, drains, arrives and polls
+        if (threadIdx.x < WP_RPB) {
+            const unsigned long long bits = __builtin_bit_cast(unsigned long long, ybuf[threadIdx.x]);
+            __hip_atomic_store(((wp_u64*)xb) + (size_t)blockIdx.x * WP_RPB + threadIdx.x, bits, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);          // global_store_dwordx2 sc1: one line, one instruction
         }
-        *lds_flag = ok;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the stores are through before the arrival below
+        if (threadIdx.x == 0) {
+            ++b.epoch;
+            const unsigned g = blockIdx.x % b.ngroups;
+            const unsigned old = __hip_atomic_fetch_add(((wp_u32*)b.set) + g * WP_BAR_STRIDE, 1u, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1 == b.epoch * b.gsize)
+                (void)__hip_atomic_fetch_add(((wp_u32*)b.set) + 8 * WP_BAR_STRIDE, 1u, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = b.epoch * b.ngroups;
+            unsigned spins = 0;
+            int ok = 1;
+            while (__hip_atomic_load(((wp_u32*)b.set) + 8 * WP_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+                   want) {
+                if (++spins > WP_SPIN_CAP ||
+                    __hip_atomic_load(((wp_u32*)b.set) + 9 * WP_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    __hip_atomic_store(((wp_u32*)b.set) + 9 * WP_BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            *lds_flag = ok;
+        }
     }
-    __syncthreads();
-    __threadfence();                                // acquire, on every wave: the other blocks' rows
+    __syncthreads();                                // between the poll and EVERY load of the handed-off bytes
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, xbytes, 0x00020000);
+#pragma unroll
+    for (int kk = 0; kk < PER / 2; ++kk) {
+        const int pair = kk * WP_THREADS + (int)threadIdx.x;
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, pair * 16, 0, WP_AUX_SC1);   // out of range: zeros
+        v[2 * kk] = __builtin_bit_cast(double, ((unsigned long long)q.y << 32) | q.x);
+        v[2 * kk + 1] = __builtin_bit_cast(double, ((unsigned long long)q.w << 32) | q.z);
+    }
     return *lds_flag != 0;
 }
 
-// rows [r0, r1) of y = alpha G x + beta x; x in LDS, the block's rows of G in LDS (GLDS) or in global memory
+// rows [r0, r1) of y = alpha G x + beta x -> ybuf[row - r0] (LDS; rows beyond r1 up to r0 + WP_RPB: 0); x in LDS,
+// the block's rows of G in LDS (GLDS) or in global memory
 template <bool GLDS>
 __device__ inline void wp_matvec(const double* __restrict__ G, const double* gs, int ld, int r0, int r1,
-                                 const double* xs, double alpha, double beta, double* __restrict__ y) {
+                                 const double* xs, double alpha, double beta, double* ybuf) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = r0 + wave; row < r1; row += WP_THREADS / 64) {
-        const double* g = GLDS ? gs + (size_t)(row - r0) * ld : G + (size_t)row * ld;
+    for (int row = r0 + wave; row < r0 + WP_RPB; row += WP_THREADS / 64) {
         double acc = 0.0;
-        for (int j = lane; j < ld; j += 64) acc = __builtin_fma(g[j], xs[j], acc);
+        if (row < r1) {
+            const double* g = GLDS ? gs + (size_t)(row - r0) * ld : G + (size_t)row * ld;
+            for (int j = lane; j < ld; j += 64) acc = __builtin_fma(g[j], xs[j], acc);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (lane == 0) y[row] = alpha * acc + beta * xs[row];
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        }
+        if (lane == 0) ybuf[row - r0] = row < r1 ? alpha * acc + beta * xs[row] : 0.0;
     }
 }
 
@@ -694,40 +734,40 @@ __device__ inline void wp_publish(int* pin, int done, int iters) {
 
 // (rho G + reg I) w = rho q by CG, warm-started from w (w_LBFGS.py:31-53 solves the same system by L-BFGS-B)
 template <bool GLDS, int PER>
-__global__ __launch_bounds__(WP_THREADS) void k_cg_persist(const double* __restrict__ G, int ld, int rpb,
-                                                            const double* __restrict__ q, double rho, double reg,
-                                                            double tol, int max_iter, double* __restrict__ w,
-                                                            double* x0, double* x1, double* __restrict__ Gw_out,
-                                                            unsigned* bar, int parity, int* pin) {
-    extern __shared__ double wp_lds[];
+__global__ __launch_bounds__(WP_THREADS) void k_cg_persist(const double* __restrict__ G, int ld, const double* __restrict__ q,
+                                                            double rho, double reg, double tol, int max_iter,
+                                                            double* __restrict__ w, double* x0, double* x1, int xbytes,
+                                                            double* __restrict__ Gw_out, unsigned* bar, int parity, int* pin) {
+    extern __shared__ __attribute__((aligned(16))) double wp_lds[];
     double* xs = wp_lds;                       // ld
     double* red = wp_lds + ld;                 // 16 (block sums)
-    int* flag = reinterpret_cast<int*>(red + 16);
-    double* gs = red + 32;                     // rpb * ld
-    const int r0 = blockIdx.x * rpb, r1 = min(ld, r0 + rpb);
+    double* ybuf = red + 16;                   // WP_RPB
+    int* flag = reinterpret_cast<int*>(ybuf + WP_RPB);
+    double* gs = ybuf + WP_RPB + 16;           // WP_RPB * ld
+    const int r0 = blockIdx.x * WP_RPB, r1 = min(ld, r0 + WP_RPB);
     WpBarrier b = wp_barrier_init(bar, parity);
     wp_stage_rows<GLDS>(G, gs, ld, r0, r1);
     double wj[PER], rj[PER], pj[PER], aj[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int j = k * WP_THREADS + threadIdx.x;
+        const int j = wp_idx(k);
         wj[k] = (j < ld) ? w[j] : 0.0;
         if (j < ld) xs[j] = wj[k];
     }
     __syncthreads();
-    wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, rho, reg, x0);          // A w
+    wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, rho, reg, ybuf);          // A w
     int iters = 0, done = 0, ok = 1;
     double rr = 0.0, thr = 0.0;
-    if (!wp_sync(b, flag)) ok = 0;
+    if (!wp_exchange<PER>(b, ybuf, x0, xbytes, aj, flag)) ok = 0;
     if (ok) {
         double acc[2] = {0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int j = k * WP_THREADS + threadIdx.x;
+            const int j = wp_idx(k);
             rj[k] = pj[k] = 0.0;
             if (j < ld) {
                 const double bb = rho * q[j];
-                rj[k] = bb - x0[j];
+                rj[k] = bb - aj[k];
                 pj[k] = rj[k];
                 acc[0] += rj[k] * rj[k];
                 acc[1] += bb * bb;
@@ -741,23 +781,18 @@ __global__ __launch_bounds__(WP_THREADS) void k_cg_persist(const double* __restr
     while (ok && !done && iters < max_iter) {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int j = k * WP_THREADS + threadIdx.x;
+            const int j = wp_idx(k);
             if (j < ld) xs[j] = pj[k];
         }
         __syncthreads();
-        double* xb = (iters & 1) ? x0 : x1;
-        wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, rho, reg, xb);      // A p
-        if (!wp_sync(b, flag)) {
+        wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, rho, reg, ybuf);      // A p
+        if (!wp_exchange<PER>(b, ybuf, (iters & 1) ? x0 : x1, xbytes, aj, flag)) {
             ok = 0;
             break;
         }
         double a1[1] = {0.0};
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int j = k * WP_THREADS + threadIdx.x;
-            aj[k] = (j < ld) ? xb[j] : 0.0;
-            a1[0] += pj[k] * aj[k];
-        }
+        for (int k = 0; k < PER; ++k) a1[0] += pj[k] * aj[k];        // (elements beyond ld: p = 0 and A p = 0)
         rbl::block_sum<1, WP_THREADS>(a1, red);
         const double alpha = (a1[0] > 0.0) ? rr / a1[0] : 0.0;
         double a2[1] = {0.0};
@@ -779,17 +814,19 @@ __global__ __launch_bounds__(WP_THREADS) void k_cg_persist(const double* __restr
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int j = k * WP_THREADS + threadIdx.x;
+            const int j = wp_idx(k);
             if (j < ld) xs[j] = wj[k];
         }
         __syncthreads();
-        wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, Gw_out);  // G w of the solution (rho prediction)
+        wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, ybuf);      // G w of the solution (rho prediction)
+        __syncthreads();
+        if (threadIdx.x < r1 - r0) Gw_out[r0 + threadIdx.x] = ybuf[threadIdx.x];
     }
     if (blockIdx.x == 0) {
         if (ok) {
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
-                const int j = k * WP_THREADS + threadIdx.x;
+                const int j = wp_idx(k);
                 if (j < ld) w[j] = wj[k];
             }
         }
@@ -800,48 +837,49 @@ __global__ __launch_bounds__(WP_THREADS) void k_cg_persist(const double* __restr
 
 // smoothed-l1 w-step: the preconditioned nonlinear CG of k_ncg_init / k_ncg_update in one launch
 template <bool GLDS, int PER>
-__global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __restrict__ G, int ld, int rpb,
-                                                             const double* __restrict__ q, NcgParams P, int max_iter,
-                                                             double* __restrict__ w, double* x0, double* x1,
-                                                             double* __restrict__ Gw_out, unsigned* bar, int parity,
-                                                             int* pin) {
-    extern __shared__ double wp_lds[];
+__global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __restrict__ G, int ld, const double* __restrict__ q,
+                                                             NcgParams P, int max_iter, double* __restrict__ w, double* x0,
+                                                             double* x1, int xbytes, double* __restrict__ Gw_out, unsigned* bar,
+                                                             int parity, int* pin) {
+    extern __shared__ __attribute__((aligned(16))) double wp_lds[];
     double* xs = wp_lds;
     double* red = wp_lds + ld;
-    int* flag = reinterpret_cast<int*>(red + 16);
-    double* gs = red + 32;
-    const int r0 = blockIdx.x * rpb, r1 = min(ld, r0 + rpb);
+    double* ybuf = red + 16;
+    int* flag = reinterpret_cast<int*>(ybuf + WP_RPB);
+    double* gs = ybuf + WP_RPB + 16;
+    const int r0 = blockIdx.x * WP_RPB, r1 = min(ld, r0 + WP_RPB);
     WpBarrier b = wp_barrier_init(bar, parity);
     wp_stage_rows<GLDS>(G, gs, ld, r0, r1);
     double wj[PER], gwj[PER], pj[PER], sj[PER], gdj[PER], qj[PER], gpj[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int j = k * WP_THREADS + threadIdx.x;
+        const int j = wp_idx(k);
         wj[k] = (j < ld) ? w[j] : 0.0;
         qj[k] = (j < ld) ? q[j] : 0.0;
         gdj[k] = (j < ld) ? G[(size_t)j * ld + j] : 1.0;
         if (j < ld) xs[j] = wj[k];
     }
     __syncthreads();
-    wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, x0);          // G w
+    wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, ybuf);          // G w
     int iters = 0, done = 0, ok = 1;
     double gs_old = 0.0, thr = 0.0, stalled = 0.0;
-    if (!wp_sync(b, flag)) ok = 0;
+    if (!wp_exchange<PER>(b, ybuf, x0, xbytes, gwj, flag)) ok = 0;
     if (ok) {
         double acc[1] = {0.0};
         double gmax = 0.0, qmax = 0.0;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int j = k * WP_THREADS + threadIdx.x;
-            gwj[k] = sj[k] = pj[k] = 0.0;
+            const int j = wp_idx(k);
+            sj[k] = pj[k] = 0.0;
             if (j < ld) {
-                gwj[k] = x0[j];
                 const double g = P.rho * (gwj[k] - qj[k]) + hub_g(wj[k], P.reg, P.t);
                 sj[k] = precond_inv(P.rho, gdj[k], hub_c(wj[k], P.reg, P.t)) * g;
                 pj[k] = -sj[k];
                 acc[0] += g * sj[k];
                 gmax = fmax(gmax, fabs(g));
                 qmax = fmax(qmax, P.rho * fabs(qj[k]));
+            } else {
+                gwj[k] = 0.0;
             }
         }
         rbl::block_sum<1, WP_THREADS>(acc, red);
@@ -854,13 +892,12 @@ __global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __rest
     while (ok && !done && iters < max_iter) {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int j = k * WP_THREADS + threadIdx.x;
+            const int j = wp_idx(k);
             if (j < ld) xs[j] = pj[k];
         }
         __syncthreads();
-        double* xb = (iters & 1) ? x0 : x1;
-        wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, xb);      // G p
-        if (!wp_sync(b, flag)) {
+        wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, ybuf);      // G p
+        if (!wp_exchange<PER>(b, ybuf, (iters & 1) ? x0 : x1, xbytes, gpj, flag)) {
             ok = 0;
             break;
         }
@@ -868,8 +905,6 @@ __global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __rest
         double a3[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int j = k * WP_THREADS + threadIdx.x;
-            gpj[k] = (j < ld) ? xb[j] : 0.0;
             const double lin = P.rho * (gwj[k] - qj[k]);
             a3[0] += lin * pj[k];
             a3[1] += pj[k] * gpj[k];
@@ -904,7 +939,7 @@ __global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __rest
         double gmax = 0.0;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int j = k * WP_THREADS + threadIdx.x;
+            const int j = wp_idx(k);
             if (j < ld) {
                 wj[k] += alpha * pj[k];
                 gwj[k] += alpha * gpj[k];
@@ -932,17 +967,19 @@ __global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __rest
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int j = k * WP_THREADS + threadIdx.x;
+            const int j = wp_idx(k);
             if (j < ld) xs[j] = wj[k];
         }
         __syncthreads();
-        wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, Gw_out);
+        wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, ybuf);
+        __syncthreads();
+        if (threadIdx.x < r1 - r0) Gw_out[r0 + threadIdx.x] = ybuf[threadIdx.x];
     }
     if (blockIdx.x == 0) {
         if (ok) {
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
-                const int j = k * WP_THREADS + threadIdx.x;
+                const int j = wp_idx(k);
                 if (j < ld) w[j] = wj[k];
             }
         }
@@ -953,45 +990,30 @@ __global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __rest
 
 struct WpPlan {
     bool ok, glds;
-    int rpb, nblocks;
+    int nblocks, xbytes;
     size_t lds_bytes;
 };
 
-// launch shape of the persistent w-step: rows per block, G rows in LDS when they fit
+// launch shape of the persistent w-step: WP_RPB rows per block, G rows in LDS when they fit
 WpPlan wp_plan(int64_t ld) {
     WpPlan p{false, false, 0, 0, 0};
     static const int enabled = [] {
         const char* e = getenv("RBL_WSTEP_PERSIST");
         return (e && e[0] == '0') ? 0 : 1;
     }();
-    static const int rpb_env = [] {
-        const char* e = getenv("RBL_WPERSIST_RPB");
-        return e ? atoi(e) : 0;
-    }();
-    if (!enabled || ld > (int64_t)WP_THREADS * WP_PER || ld < 4) return p;
+    if (!enabled || ld > WSTEP_PERSIST_MAX_LD || ld < 4) return p;
     static const int cus = [] {
         int dev = 0, c = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
         return c < 1 ? 1 : c;
     }();
-    int rpb = rpb_env > 0 ? rpb_env : 16;
-    // at most one block per CU: all blocks resident at once (the device-wide barrier needs that)
-    while ((ld + rpb - 1) / rpb > cus) rpb *= 2;
-    const size_t fixed = sizeof(double) * ((size_t)ld + 32);
-    const size_t rows = sizeof(double) * (size_t)rpb * (size_t)ld;
-    p.glds = fixed + rows <= 150 * 1024;
-    if (!p.glds && rpb_env <= 0) {
-        // G rows do not fit: fewer rows per block if that keeps one block per CU
-        int r2 = rpb;
-        while (r2 > 1 && fixed + sizeof(double) * (size_t)r2 * ld > 150 * 1024) r2 /= 2;
-        if ((ld + r2 - 1) / r2 <= cus && fixed + sizeof(double) * (size_t)r2 * ld <= 150 * 1024) {
-            rpb = r2;
-            p.glds = true;
-        }
-    }
-    p.rpb = rpb;
-    p.nblocks = (int)((ld + rpb - 1) / rpb);
-    p.lds_bytes = fixed + (p.glds ? sizeof(double) * (size_t)rpb * ld : 0);
+    p.nblocks = (int)((ld + WP_RPB - 1) / WP_RPB);
+    if (p.nblocks > cus) return p;   // at most one block per CU: all blocks resident at once (the device-wide wait needs that)
+    const size_t fixed = sizeof(double) * ((size_t)ld + 16 + WP_RPB + 16);
+    const size_t rows = sizeof(double) * (size_t)WP_RPB * (size_t)ld;
+    p.glds = fixed + rows <= 156 * 1024;
+    p.lds_bytes = fixed + (p.glds ? rows : 0);
+    p.xbytes = p.nblocks * WP_RPB * (int)sizeof(double);
     p.ok = true;
     return p;
 }
@@ -1003,7 +1025,7 @@ int wp_set_lds(K kernel, size_t bytes) {
     return RBL_OK;
 }
 
-// returns RBL_OK with *status = 1 converged / 0 iteration cap / -1 launch failure / -2 barrier gave up
+// returns RBL_OK with *status = 1 converged / 0 iteration cap / -1 launch failure / -2 a wait gave up
 int run_cg_persist(const WpPlan& pl, const double* G, int64_t ld, const double* q, double rho, double reg, double tol,
                    int max_iter, double* w, WstepWorkspace& ws, bool want_Gw, int* status, int* iters, hipStream_t s) {
     int* pin = ws.pin + 4;
@@ -1011,6 +1033,7 @@ int run_cg_persist(const WpPlan& pl, const double* G, int64_t ld, const double* 
     const int parity = ws.bar_parity;
     ws.bar_parity ^= 1;
     double* gw = want_Gw ? ws.Gy : nullptr;
+    double *x0 = ws.xch, *x1 = ws.xch + WSTEP_XCH_DOUBLES / 2;
 #define RBL_CG_PERSIST(GL, PR)                                                                                           \
     do {                                                                                                                 \
         static size_t lds_set = 0; /* (one attribute call per instantiation and size, not per launch) */                 \
@@ -1018,8 +1041,8 @@ int run_cg_persist(const WpPlan& pl, const double* G, int64_t ld, const double* 
             RBL_TRY(wp_set_lds(k_cg_persist<GL, PR>, pl.lds_bytes));                                                     \
             lds_set = pl.lds_bytes;                                                                                      \
         }                                                                                                                \
-        hipLaunchKernelGGL((k_cg_persist<GL, PR>), dim3(pl.nblocks), dim3(WP_THREADS), pl.lds_bytes, s, G, (int)ld, pl.rpb, q, \
-                           rho, reg, tol, max_iter, w, ws.r, ws.p, gw, ws.bar, parity, pin);                             \
+        hipLaunchKernelGGL((k_cg_persist<GL, PR>), dim3(pl.nblocks), dim3(WP_THREADS), pl.lds_bytes, s, G, (int)ld, q, rho, \
+                           reg, tol, max_iter, w, x0, x1, pl.xbytes, gw, ws.bar, parity, pin);                           \
     } while (0)
     const bool narrow = ld <= 4 * WP_THREADS;
     if (pl.glds && narrow) RBL_CG_PERSIST(true, 4);
@@ -1042,6 +1065,7 @@ int run_ncg_persist(const WpPlan& pl, const double* G, int64_t ld, const double*
     const int parity = ws.bar_parity;
     ws.bar_parity ^= 1;
     double* gw = want_Gw ? ws.Gy : nullptr;
+    double *x0 = ws.xch, *x1 = ws.xch + WSTEP_XCH_DOUBLES / 2;
 #define RBL_NCG_PERSIST(GL, PR)                                                                                          \
     do {                                                                                                                 \
         static size_t lds_set = 0;                                                                                       \
@@ -1049,8 +1073,8 @@ int run_ncg_persist(const WpPlan& pl, const double* G, int64_t ld, const double*
             RBL_TRY(wp_set_lds(k_ncg_persist<GL, PR>, pl.lds_bytes));                                                    \
             lds_set = pl.lds_bytes;                                                                                      \
         }                                                                                                                \
-        hipLaunchKernelGGL((k_ncg_persist<GL, PR>), dim3(pl.nblocks), dim3(WP_THREADS), pl.lds_bytes, s, G, (int)ld, pl.rpb, q, \
-                           P, max_iter, w, ws.r, ws.p, gw, ws.bar, parity, pin);                                         \
+        hipLaunchKernelGGL((k_ncg_persist<GL, PR>), dim3(pl.nblocks), dim3(WP_THREADS), pl.lds_bytes, s, G, (int)ld, q, P, \
+                           max_iter, w, x0, x1, pl.xbytes, gw, ws.bar, parity, pin);                                     \
     } while (0)
     const bool narrow = ld <= 4 * WP_THREADS;
     if (pl.glds && narrow) RBL_NCG_PERSIST(true, 4);
@@ -1069,7 +1093,7 @@ int run_ncg_persist(const WpPlan& pl, const double* G, int64_t ld, const double*
 bool ncg_persist_try(const double* G, int64_t ld, const double* q, NcgParams P, int max_iter, double* w,
                      WstepWorkspace& ws, bool want_Gw, int* status, int* iters, hipStream_t s, int* rc) {
     const WpPlan pl = wp_plan(ld);
-    if (!pl.ok || !ws.bar) return false;
+    if (!pl.ok || !ws.bar || !ws.xch) return false;
     *rc = run_ncg_persist(pl, G, ld, q, P, max_iter, w, ws, want_Gw, status, iters, s);
     return true;
 }
@@ -1093,7 +1117,7 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
     }
     if (wstep == RBL_WSTEP_L2) {
         const WpPlan pl = wp_plan(ld);
-        if (pl.ok && ws.bar) {
+        if (pl.ok && ws.bar && ws.xch) {
             // the whole CG in one persistent launch (k_cg_persist)
             int status = 0, it = 0;
             RBL_TRY(run_cg_persist(pl, G, ld, q, rho, reg, tol, max_inner < 20000 ? max_inner : 20000, w, ws, want_Gw, &status,
