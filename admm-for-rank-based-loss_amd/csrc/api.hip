@@ -222,12 +222,19 @@ int alloc_pav(PavWorkspace& pw, int64_t n) {
     RBL_TRY(dev_alloc(&pw.counters, 4));
     RBL_TRY(dev_alloc(&pw.partials, (size_t)reduce_blocks() * 4));
     RBL_TRY(dev_alloc(&pw.branch, 1));
+    pw.ex = PavExtras{};
+    RBL_TRY(dev_alloc(&pw.ex.bar, pav_bar_uints()));
+    RBL_HIP(hipMemset(pw.ex.bar, 0, sizeof(unsigned) * pav_bar_uints()));
+    RBL_TRY(dev_alloc(&pw.ex.big, (size_t)pav_big_recs()));
+    RBL_TRY(dev_alloc(&pw.ex.fpart, (size_t)pav_fpart_doubles(n)));
+    pw.ex.spec = 1;   // EHRM: branch b on every ADMM trajectory seen; corrected by the first exact test
     return RBL_OK;
 }
 
 void free_pav(PavWorkspace& pw) {
     dev_free(pw.ms); dev_free(pw.u); dev_free(pw.locx_m); dev_free(pw.chunk_m); dev_free(pw.cph_m);
     dev_free(pw.cpl_m); dev_free(pw.recs); dev_free(pw.counters); dev_free(pw.partials); dev_free(pw.branch);
+    dev_free(pw.ex.bar); dev_free(pw.ex.big); dev_free(pw.ex.fpart);
     pw = PavWorkspace{};
 }
 
@@ -372,14 +379,29 @@ int z_step_sorted(rbl_solver* h, const double* msrc, double rho) {
     RBL_TRY(launch_radix_sort(h->sw, nt, true, s));
     RBL_TRY(launch_unflip_prefix(h->sw.keys[0], nt, h->pw.ms, h->pw.locx_m, h->pw.chunk_m, h->pw.cph_m, h->pw.cpl_m, s));
     const bool ehrm = h->cfg.weight_function == RBL_W_EHRM;
-    // EHRM: the branch test solves both element prox problems; they are level 0 of the tree as well
-    double* u0a = ehrm ? h->pw.u : nullptr;
-    double* u0b = ehrm ? (double*)h->sw.keys[1] : nullptr;   // free once the sort is done
-    if (ehrm)
+    // EHRM: the branch of the previous iteration is speculated and the exact test rides on the bottom kernel
+    // (pav.hip: k_pav_bottom<0, true>).  RBL_EHRM_SPEC=0 / 1: the first speculation (tests force a wrong one);
+    // RBL_EHRM_SPEC=-1: round 2's form - a pass of its own solves both element prox problems (k_ehrm_fvals), the tree
+    // reads the chosen one as its level 0
+    int spec_env = 2;
+    if (ehrm) {
+        const char* e = getenv("RBL_EHRM_SPEC");   // (read per z-step: the tests switch it between handles)
+        if (e) spec_env = atoi(e);
+    }
+    PavExtras ex = h->pw.ex;
+    ex.num_cu = h->num_cu;
+    ex.B = h->cfg.B;
+    const bool spec = ehrm && spec_env != -1;
+    if (!spec) ex.fpart = nullptr;
+    if (spec && h->iter == 0 && (spec_env == 0 || spec_env == 1)) ex.spec = spec_env;
+    double* u0a = (ehrm && !spec) ? h->pw.u : nullptr;
+    double* u0b = (ehrm && !spec) ? (double*)h->sw.keys[1] : nullptr;   // free once the sort is done
+    if (ehrm && !spec)
         RBL_TRY(launch_ehrm_branch(nt, h->sigma_a, h->sigma_b, h->cfg.B, rho, h->pw.ms, h->pw.partials, h->pw.branch,
                                    -1, s, u0a, u0b));
     RBL_TRY(launch_pav_tree(h->cfg.loss, nt, rho, h->pw.ms, h->sigma_a, h->sigma_b, h->pw.u, h->pa, h->pb, h->pm,
-                            ehrm ? h->pw.branch : nullptr, h->pw.recs, h->pw.counters, s, u0a, u0b));
+                            ehrm ? h->pw.branch : nullptr, h->pw.recs, h->pw.counters, s, u0a, u0b, &ex));
+    h->pw.ex.bar_parity = ex.bar_parity;
     RBL_TRY(launch_scatter_z(nt, h->pw.u, h->sw.vals[0], ehrm ? h->pw.branch : nullptr, h->cfg.B, ehrm ? 1 : 0, rho,
                              h->lam, h->z, nullptr, h->off, h->n, s));
     return RBL_OK;
@@ -845,8 +867,10 @@ int rbl_set_data(rbl_solver* h, const double* X, const double* y, int64_t ldx) {
 
 int rbl_synth_local(rbl_solver* h, uint64_t seed, double class_sep, double flip_y) {
     RBL_ENTER(h);
-    // positions of the 2 informative + 2 redundant columns and the 2x2 mixing matrix:
-    // a small host-side LCG keyed by the seed (identical on every rank)
+    // positions of the 2 informative + 2 redundant columns, the 2x2 mixing matrix of the redundant ones, the four
+    // clusters' covariance matrices A_k (entries uniform in (-1, 1)) and which hypercube vertex each cluster sits on
+    // (a random permutation; cluster k belongs to class k % 2) - make_classification's geometry draws - from a small
+    // host-side LCG keyed by the seed (identical on every rank)
     uint64_t st = seed * 6364136223846793005ull + 1442695040888963407ull;
     auto next = [&]() {
         st = st * 6364136223846793005ull + 1442695040888963407ull;
@@ -867,8 +891,15 @@ int rbl_synth_local(rbl_solver* h, uint64_t seed, double class_sep, double flip_
     }
     double mix[4];
     for (int k = 0; k < 4; ++k) mix[k] = 2.0 * ((double)next() / 2147483648.0) - 1.0;
-    RBL_TRY(launch_synth(h->storage, h->D, h->n, h->ld, h->d, h->off, seed, class_sep, flip_y, special, mix, h->ysign,
-                         h->stream));
+    double A16[16];
+    for (int k = 0; k < 16; ++k) A16[k] = 2.0 * ((double)next() / 2147483648.0) - 1.0;
+    int vertex[4] = {0, 1, 2, 3};
+    for (int i = 3; i > 0; --i) {
+        const int j = (int)(next() % (uint32_t)(i + 1));
+        std::swap(vertex[i], vertex[j]);
+    }
+    RBL_TRY(launch_synth(h->storage, h->D, h->n, h->ld, h->d, h->off, seed, class_sep, flip_y, special, mix, A16, vertex,
+                         h->ysign, h->stream));
     // column sums / sums of squares of the local rows -> colstats[0 .. 2 ld)
     RBL_TRY(launch_colstats(h->storage, h->D, h->n, h->ld, h->slab, h->colstats, h->colstats + h->ld, h->num_cu,
                             h->stream));
@@ -1352,6 +1383,7 @@ static __global__ void k_pack_stats(const double* __restrict__ red, const double
     hstat[6] = pred ? pred[1] : 0.0;
     hstat[7] = branch ? (double)branch[0] : -1.0;
     hstat[8] = counters ? (double)counters[0] : 0.0;
+    hstat[10] = counters ? (double)counters[3] : 0.0;   // persistent upper-level PAV kernel: 1 = it did not complete
     __threadfence_system();
     reinterpret_cast<volatile int*>(hstat + 15)[0] = seq;   // written last: the host polls this word
 }
@@ -1402,6 +1434,11 @@ int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
         rbl_set_error("distributed z-step: a seam search did not finish within its rounds");
         return RBL_ERR_STATE;
     }
+    if (hs[10] != 0.0) {
+        rbl_set_error("z-step: the upper-level PAV kernel did not complete (a wait gave up or its fill list overflowed)");
+        return RBL_ERR_HIP;
+    }
+    if (br >= 0) h->pw.ex.spec = br;   // EHRM: the next iteration speculates the branch this one took
     const double primal = std::sqrt(r[0] > 0.0 ? r[0] : 0.0);   // algorithms.py:135
     const double dual = std::sqrt(r2[0] > 0.0 ? r2[0] : 0.0);   // algorithms.py:136
     double objective = NAN;
@@ -1747,9 +1784,13 @@ int rbl_zd_pav(rbl_solver* h, const void* fvals_total_dev) {
     const bool ehrm = h->cfg.weight_function == RBL_W_EHRM;
     if (ehrm) RBL_TRY(launch_ehrm_pick((const double*)fvals_total_dev, h->pw.branch, s));
     const Prefix pm{h->pw.locx_m, h->pw.cph_m, h->pw.cpl_m};
+    PavExtras ex = h->pw.ex;      // the chunk's upper levels in one launch; the branch comes from the sums over ALL ranks
+    ex.num_cu = h->num_cu;
+    ex.fpart = nullptr;
     RBL_TRY(launch_pav_tree(h->cfg.loss, h->zd_n, h->step_rho, h->pw.ms, h->sigma_a + h->zd_off, h->sigma_b + h->zd_off,
                             h->pw.u, h->zpa, h->zpb, pm, ehrm ? h->pw.branch : nullptr, h->pw.recs, h->pw.counters, s,
-                            ehrm ? h->pw.u : nullptr, ehrm ? (const double*)h->sw.keys[1] : nullptr));
+                            ehrm ? h->pw.u : nullptr, ehrm ? (const double*)h->sw.keys[1] : nullptr, &ex));
+    h->pw.ex.bar_parity = ex.bar_parity;
     return RBL_OK;
 }
 
@@ -2240,13 +2281,35 @@ static int k_pav_common(int loss, int64_t n, const double* sigma_a, const double
     double* partials = sc.alloc<double>((size_t)reduce_blocks() * 4);
     int* branch = sc.alloc<int>(1);
     SC_CHECK(recs && counters && partials && branch);
+    PavExtras ex{};
+    ex.bar = sc.alloc<unsigned>(pav_bar_uints());
+    ex.big = sc.alloc<SeamRec>((size_t)pav_big_recs());
+    ex.fpart = sc.alloc<double>((size_t)pav_fpart_doubles(n));
+    SC_CHECK(ex.bar && ex.big && ex.fpart);
+    RBL_HIP(hipMemset(ex.bar, 0, sizeof(unsigned) * pav_bar_uints()));
+    {
+        int dev = 0, cus = 0;
+        RBL_HIP(hipGetDevice(&dev));
+        RBL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        ex.num_cu = cus;
+    }
+    ex.B = B;
+    ex.spec = 1;
+    {
+        const char* e = getenv("RBL_EHRM_SPEC");   // 0 / 1: the speculated branch; -1: round 2's separate pass
+        if (e && (atoi(e) == 0 || atoi(e) == 1)) ex.spec = atoi(e);
+        // a forced branch (the tests pin both) and RBL_EHRM_SPEC=-1 go through the separate test; the automatic choice
+        // through the speculation inside the bottom kernel
+        if (!ehrm || branch_in >= 0 || (e && atoi(e) == -1)) ex.fpart = nullptr;
+    }
     RBL_HIP(hipMemset(recs, 0xff, sizeof(SeamRec) * (size_t)pav_num_recs(n)));   // no hints
     RBL_TRY(launch_prefix(sa, n, lx[0], ch[0], cph[0], cpl[0], sc.s));
     RBL_TRY(launch_prefix(sb, n, lx[1], ch[1], cph[1], cpl[1], sc.s));
     RBL_TRY(launch_prefix(ms, n, lx[2], ch[2], cph[2], cpl[2], sc.s));
     Prefix pa{lx[0], cph[0], cpl[0]}, pb{lx[1], cph[1], cpl[1]}, pm{lx[2], cph[2], cpl[2]};
-    if (ehrm) RBL_TRY(launch_ehrm_branch(n, sa, sb, B, rho, ms, partials, branch, branch_in, sc.s));
-    RBL_TRY(launch_pav_tree(loss, n, rho, ms, sa, sb, u, pa, pb, pm, ehrm ? branch : nullptr, recs, counters, sc.s));
+    if (ehrm && !ex.fpart) RBL_TRY(launch_ehrm_branch(n, sa, sb, B, rho, ms, partials, branch, branch_in, sc.s));
+    RBL_TRY(launch_pav_tree(loss, n, rho, ms, sa, sb, u, pa, pb, pm, ehrm ? branch : nullptr, recs, counters, sc.s, nullptr,
+                            nullptr, &ex));
     // identity permutation scatter applies the EHRM clip
     std::vector<u32> idh((size_t)n);
     for (int64_t i = 0; i < n; ++i) idh[(size_t)i] = (u32)i;
@@ -2255,11 +2318,16 @@ static int k_pav_common(int loss, int64_t n, const double* sigma_a, const double
     SC_CHECK(idd && zz);
     RBL_TRY(launch_scatter_z(n, u, idd, ehrm ? branch : nullptr, B, ehrm, rho, nullptr, zz, nullptr, 0, n, sc.s));
     RBL_HIP(hipMemcpyAsync(out, zz, sizeof(double) * n, hipMemcpyDeviceToHost, sc.s));
-    unsigned mc = 0;
+    unsigned mc4[4] = {0, 0, 0, 0};
     int br = -1;
-    RBL_HIP(hipMemcpyAsync(&mc, counters, sizeof(unsigned), hipMemcpyDeviceToHost, sc.s));
+    RBL_HIP(hipMemcpyAsync(mc4, counters, sizeof(mc4), hipMemcpyDeviceToHost, sc.s));
     if (ehrm) RBL_HIP(hipMemcpyAsync(&br, branch, sizeof(int), hipMemcpyDeviceToHost, sc.s));
     RBL_HIP(hipStreamSynchronize(sc.s));
+    if (mc4[3] != 0) {
+        rbl_set_error("PAV: the upper-level kernel did not complete (a wait gave up or its fill list overflowed)");
+        return RBL_ERR_HIP;
+    }
+    const unsigned mc = mc4[0];
     if (n_merges) *n_merges = mc;
     if (branch_out) *branch_out = br;
     return RBL_OK;

@@ -19,6 +19,7 @@
 // double-double) so a small block's sum is not a difference of two n-sized prefixes.
 #include "rbl_internal.h"
 #include "device_math.h"
+#include "grid_sync.h"
 
 namespace {
 
@@ -503,39 +504,91 @@ __device__ inline void seam_merge(const Acc& ac, long long L0, long long seam, l
 // One workgroup per tile of PB_TILE sorted positions: element prox (the tree's level 0),
 // tile-local prefix sums and the levels with segments up to PB_TILE, all in LDS; one global
 // read of (m, sigma) and one write of u per position.
+//
+// Levels 1-3 (segments of PB_PER = 8 positions) are ONE step (round 3): every thread runs the classic sequential
+// stack PAV over its own 8 consecutive positions - block sums from the tile's prefix arrays, the stack a bit mask of
+// block starts - which leaves exactly what three tree levels leave (the isotonic solution of a segment is unique;
+// the block values are the same block_value() of the same prefix differences).  With smooth rank weights (extremile,
+// esrm, EHRM's CPT weights) the solution has thousands of short blocks (pairs, triples) spread over the whole upper
+// part of the order: as tree merges each of them cost one divergent seam_merge() - searches included - per wave and
+// level (k_pav_bottom 381 us at 6.25 M EHRM positions against 141 us for a superquantile problem of the same size);
+// sequentially a pair is one comparison and one block solve.
+//
+// EHRM with a SPECULATED branch (SPEC): the singleton-stage scalar test of PAV_cpt.py:205-226 needs
+// f1 = sum phi_a(min(prox_a(m), B)) and f2 = sum phi_b(max(prox_b(m), B)) over all positions.  Round 2 computed both
+// element prox vectors in a pass of its own (k_ehrm_fvals, 182 us at 6.25 M), stored both, and the tree read the one
+// the test chose.  The branch is the same from one ADMM iteration to the next (b on every trajectory seen, SURVEY
+// 3.4-b), so the tree is built for the branch the PREVIOUS iteration took while this kernel accumulates f1 and f2 on
+// the side: the speculated branch's prox is level 0 anyway, and the other branch's clipped value is B itself - no
+// Newton solve - wherever its prox lies beyond B, i.e. m >= B + sigma_a sigmoid(B) / rho for branch a (phi_a'(B) <= 0),
+// m <= B + sigma_b sigmoid(B) / rho for branch b.  k_ehrm_pick then forms the exact test; if it contradicts the
+// speculation, the plain kernel (guard = the speculated branch: a no-op launch otherwise) rebuilds the tile for the
+// other branch before the upper levels run.
 constexpr int PB_TILE_LOG = 11;
 constexpr int PB_TILE = 1 << PB_TILE_LOG;  // 2048 positions, 48 KB of LDS
 constexpr int PB_PER = PB_TILE / PV_THREADS;
+static_assert(PB_PER == 8, "the sequential step keeps its block starts in the low 8 bits of a mask");
 
-template <int LOSS>
+template <int LOSS, bool SPEC>
 __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restrict__ ms, const double* __restrict__ sa,
                                                             const double* __restrict__ sb, const int* __restrict__ branch,
                                                             double rho, long long n, double* u_out,
                                                             u32* __restrict__ merge_counter, const double* u0a,
-                                                            const double* u0b, int wave_top) {
-    // u0a / u0b != NULL (EHRM): level 0 was computed by k_ehrm_fvals; u0a may alias u_out (a block reads
-    // and writes only its own tile)
+                                                            const double* u0b, int bflags, int skip_if_branch,
+                                                            double B, int spec, double* __restrict__ fpart) {
+    // u0a / u0b != NULL (EHRM, distributed z-step): level 0 was computed by k_ehrm_fvals; u0a may alias u_out (a block
+    // reads and writes only its own tile).  skip_if_branch >= 0: nothing to do when *branch says so (see above).
+    // SPEC: sa / sb / B / spec as described above, fpart[2 * block + {0, 1}] receive this tile's share of f1 / f2.
+    if (!SPEC && skip_if_branch >= 0 && branch && *branch == skip_if_branch) return;
+    const int wave_top = bflags & 1;
+    const bool seq_levels = !(bflags & 2);
     __shared__ double su[PB_TILE];
     __shared__ double spa[PB_TILE + 1];
     __shared__ double spm[PB_TILE + 1];
     __shared__ double wsum[2][PV_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long base = (long long)blockIdx.x * PB_TILE;
-    const double* sg = (branch && *branch) ? sb : sa;
-    const double* u0 = u0a ? ((branch && *branch) ? u0b : u0a) : nullptr;
+    const bool use_b = SPEC ? (spec != 0) : (branch && *branch);
+    const double* sg = use_b ? sb : sa;
+    const double* u0 = (!SPEC && u0a) ? (use_b ? u0b : u0a) : nullptr;
     long long nt = n - base;  // valid positions of this tile
     if (nt > PB_TILE) nt = PB_TILE;
 
     // level 0 + thread-local sums (PB_PER consecutive positions per thread)
     double ls[PB_PER], lm[PB_PER];
     double ts = 0.0, tm = 0.0;
+    double f12[2] = {0.0, 0.0};
+    const double sigB = SPEC ? rbl::sigmoid1(B) : 0.0, spB = SPEC ? rbl::softplus(B) : 0.0;
 #pragma unroll
     for (int k = 0; k < PB_PER; ++k) {
         const int i = tid * PB_PER + k;
         const bool ok = i < nt;
         ls[k] = ok ? sg[base + i] : 0.0;
         lm[k] = ok ? ms[base + i] : 0.0;
-        su[i] = ok ? (u0 ? u0[base + i] : rbl::prox_est<LOSS>(ls[k], rho, lm[k])) : 0.0;
+        if (SPEC) {
+            double x = 0.0;
+            if (ok) {
+                const double m = lm[k], sm = rbl::sigmoid1(m);
+                x = rbl::prox_bce_est(ls[k], rho, m, sm);                    // level 0 of the speculated branch
+                const double so = (use_b ? sa : sb)[base + i];               // the other branch's weight
+                // speculated branch: clipped at B from its own side; other branch: B itself wherever its prox lies beyond B
+                double os = x, oo;
+                if (use_b) {
+                    if (os <= B) os = B;                                     // PAV_cpt.py:218
+                    oo = (m >= B + so * sigB / rho) ? B : fmin(rbl::prox_bce_est(so, rho, m, sm), B);   // :211
+                } else {
+                    if (os > B) os = B;
+                    oo = (m <= B + so * sigB / rho) ? B : fmax(rbl::prox_bce_est(so, rho, m, sm), B);
+                }
+                const double fs = ls[k] * (os == B ? spB : rbl::softplus(os)) + 0.5 * rho * (os - m) * (os - m);
+                const double fo = so * (oo == B ? spB : rbl::softplus(oo)) + 0.5 * rho * (oo - m) * (oo - m);
+                f12[use_b ? 1 : 0] += fs;                                    // f1 belongs to branch a, f2 to branch b
+                f12[use_b ? 0 : 1] += fo;
+            }
+            su[i] = x;
+        } else {
+            su[i] = ok ? (u0 ? u0[base + i] : rbl::prox_est<LOSS>(ls[k], rho, lm[k])) : 0.0;
+        }
         ts += ls[k];
         tm += lm[k];
     }
@@ -571,9 +624,53 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
         spm[PB_TILE] = pm_;
     }
     __syncthreads();
+    if (SPEC) {
+        // this tile's share of the two singleton-stage sums (fixed order: deterministic)
+        rbl::block_sum<2, PV_THREADS>(f12, &wsum[0][0]);
+        if (tid == 0) {
+            fpart[2 * (long long)blockIdx.x + 0] = f12[0];
+            fpart[2 * (long long)blockIdx.x + 1] = f12[1];
+        }
+        __syncthreads();
+    }
 
     const LdsAcc ac{su, spa, spm};
     u32 merges = 0;
+    // Levels 1-3: sequential PAV over the thread's own PB_PER positions (see the header comment).  `starts`: bit j set
+    // = position j of the segment starts a block; all positions of a block hold its value.
+    if (seq_levels) {
+        const int b0 = tid * PB_PER;
+        const int cnt = (int)(nt - b0 < PB_PER ? nt - b0 : PB_PER);
+        if (cnt > 1) {
+            u32 starts = 1u;
+            double cur = su[b0];
+            int cur_s = 0;
+            for (int i = 1; i < cnt; ++i) {
+                const double xi = su[b0 + i];
+                if (cur <= xi) {                     // pav.py:105: only a strict decrease violates
+                    starts |= 1u << i;
+                    cur = xi;
+                    cur_s = i;
+                    continue;
+                }
+                int s0 = cur_s;
+                double x = block_value<LOSS>(spa[b0 + i + 1] - spa[b0 + s0], spm[b0 + i + 1] - spm[b0 + s0], (double)(i + 1 - s0), rho);
+                ++merges;
+                while (s0 > 0) {
+                    const int ps0 = 31 - __clz((int)(starts & ((1u << s0) - 1u)));   // start of the block before
+                    if (su[b0 + ps0] <= x) break;
+                    starts &= ~(1u << s0);
+                    s0 = ps0;
+                    x = block_value<LOSS>(spa[b0 + i + 1] - spa[b0 + s0], spm[b0 + i + 1] - spm[b0 + s0], (double)(i + 1 - s0), rho);
+                    ++merges;
+                }
+                for (int j = s0; j <= i; ++j) su[b0 + j] = x;
+                cur = x;
+                cur_s = s0;
+            }
+        }
+        __syncthreads();
+    }
     // Levels with short segments: the thread that merged a seam writes the pooled range itself.
     // From PB_COOP on (at most PB_TILE / (2 PB_COOP) seams per level) the pooled ranges get long
     // (up to the whole tile) and a single thread writing them would serialise the level: the
@@ -581,7 +678,7 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
     constexpr int PB_COOP = 32;
     __shared__ int rec_s[PB_TILE / (2 * PB_COOP)], rec_e[PB_TILE / (2 * PB_COOP)];
     __shared__ double rec_x[PB_TILE / (2 * PB_COOP)];
-    for (int half = 1; half < PB_TILE; half <<= 1) {
+    for (int half = seq_levels ? PB_PER : 1; half < PB_TILE; half <<= 1) {
         const int nseams = PB_TILE / (2 * half);
         const bool coop = half >= PB_COOP;
         if (wave_top && nseams <= PV_THREADS / 64) {
@@ -722,6 +819,122 @@ __global__ __launch_bounds__(256) void k_pav_fill(double* __restrict__ u, long l
     if (hi > r.e) hi = r.e;
     if (hi >= n) hi = n - 1;
     for (long long i = lo + threadIdx.x; i <= hi; i += 256) u[i] = r.x;
+}
+
+// ---------------------------------------------------------------- upper levels in ONE launch (round 3)
+// Round 2 ran two kernels per upper level (k_pav_seam_wave + k_pav_fill: 12 levels at 6 M positions = 24 launches,
+// ~22 us per level with the boundaries, 0.23-0.27 ms per z-step) although in the steady state of a solve only a few
+// of the ~n / 2048 upper seams violate at all, and what they pool are short blocks.  One persistent launch instead:
+//   phase 0   every upper seam of every level is looked at once (u[seam - 1] > u[seam]?): a bit per level that has a
+//             violating seam (`dirty`, agent-scope atomic OR);
+//   level l   is SKIPPED by every block when its bit is clear - no work, no barrier.  Otherwise one wave per seam as
+//             before (seam_merge with the 64-ary searches and the hints of the previous ADMM iteration); the merging
+//             wave writes the pooled range itself when it is short, long ranges (the first iterations pool most rows
+//             into one block) go to a list all blocks fill together after the level's barrier; a pooled range that
+//             reaches an end of its segment can make the seam of a HIGHER level at that end violate: its level's bit
+//             is set.  One device-wide barrier (grid_sync.h) per level that did work, a second one behind a
+//             cooperative fill.
+// A level's bit can only be set by phase 0 or by merges of lower levels, all of which lie before the barrier after
+// which the bit is read, so every block takes the same decisions and passes the same barriers.
+constexpr long long PU_DIRECT_FILL = 8192;    // positions a merging wave writes itself
+constexpr int PU_BIG_CAP = 4096;              // capacity of the cooperative-fill list
+
+struct PavUpperArgs {
+    SeamRec* hints;        // per level, concatenated (NULL: cold searches)
+    SeamRec* big;          // cooperative-fill list
+    u32* counters;         // [0] merges, [1] dirty levels, [2] entries of `big`, [3] status (1: a wait gave up / list overflow)
+    unsigned* bar;
+    int parity, nlevels;
+};
+
+template <int LOSS>
+__global__ __launch_bounds__(PV_THREADS) void k_pav_upper(double* __restrict__ u, long long n, Prefix pa_, Prefix pb_, Prefix pm,
+                                                           const int* branch, double rho, PavUpperArgs A) {
+    __shared__ int s_flag;
+    const int lane = threadIdx.x & 63;
+    const long long wave_id = ((long long)blockIdx.x * PV_THREADS + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * PV_THREADS) >> 6;
+    const long long tid_g = (long long)blockIdx.x * PV_THREADS + threadIdx.x, nthreads = (long long)gridDim.x * PV_THREADS;
+    rbl::GridBarrier gb = rbl::gs_init(A.bar, A.parity);
+    typedef unsigned gu32 __attribute__((address_space(1)));
+    gu32* dirty = (gu32*)(A.counters + 1);
+    gu32* bigcnt = (gu32*)(A.counters + 2);
+    // ---- phase 0: which levels have a violating seam
+    for (int l = 0; l < A.nlevels; ++l) {
+        const long long half = (long long)PB_TILE << l, nseams = (n + 2 * half - 1) / (2 * half);
+        bool any = false;
+        for (long long k = tid_g; k < nseams; k += nthreads) {
+            const long long seam = (2 * k + 1) * half;
+            if (seam < n && u[seam - 1] > u[seam]) any = true;
+        }
+        if (__ballot(any) != 0ull && lane == 0) (void)__hip_atomic_fetch_or(dirty, 1u << l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool ok = rbl::gs_barrier(gb, &s_flag);
+    u32 mask = __hip_atomic_load(dirty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u32 merges = 0, big_done = 0;
+    const WaveAcc ac{u, (branch && *branch) ? pb_ : pa_, pm};
+    long long hint_off = 0;
+    for (int l = 0; ok && l < A.nlevels; ++l) {
+        const long long half = (long long)PB_TILE << l, nseams = (n + 2 * half - 1) / (2 * half);
+        SeamRec* hints = A.hints ? A.hints + hint_off : nullptr;
+        hint_off += nseams;
+        if (!((mask >> l) & 1u)) continue;
+        for (long long k = wave_id; k < nseams; k += nwaves) {
+            const long long seam = (2 * k + 1) * half;
+            if (seam >= n || u[seam - 1] <= u[seam]) continue;   // pav.py:105 - only a strict decrease is a violation
+            long long R1 = seam + half;
+            if (R1 > n) R1 = n;
+            const long long L0 = seam - half;
+            long long s_star, e_star, hs = -1, he = -1;
+            double x, hx = __builtin_nan("");
+            if (hints) {
+                hs = hints[k].s;
+                he = hints[k].e;
+                if (hs >= 0) hx = hints[k].x;
+            }
+            seam_merge<LOSS>(ac, L0, seam, R1, rho, s_star, e_star, x, hs, he, hx);
+            if (lane == 0) {
+                ++merges;
+                if (hints) {
+                    hints[k].s = s_star;
+                    hints[k].e = e_star;
+                    hints[k].x = x;
+                }
+                // a pooled range that reaches an end of its segment changes the value next to a higher level's seam
+                u32 up = 0;
+                if (s_star == L0 && L0 > 0) up |= 1u << __builtin_ctzll((unsigned long long)(L0 >> PB_TILE_LOG));
+                if (e_star == R1 - 1 && R1 < n) up |= 1u << __builtin_ctzll((unsigned long long)(R1 >> PB_TILE_LOG));
+                if (up) (void)__hip_atomic_fetch_or(dirty, up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (e_star - s_star + 1 <= PU_DIRECT_FILL) {
+                for (long long i = s_star + lane; i <= e_star; i += 64) u[i] = x;
+            } else if (lane == 0) {
+                const u32 slot = __hip_atomic_fetch_add(bigcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot < (u32)PU_BIG_CAP) {
+                    A.big[slot].s = s_star;
+                    A.big[slot].e = e_star;
+                    A.big[slot].x = x;
+                } else {
+                    __hip_atomic_store((gu32*)(A.counters + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        ok = rbl::gs_barrier(gb, &s_flag);
+        if (!ok) break;
+        u32 nbig = __hip_atomic_load(bigcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nbig > (u32)PU_BIG_CAP) nbig = PU_BIG_CAP;
+        if (nbig > big_done) {
+            for (u32 r = big_done; r < nbig; ++r) {
+                const SeamRec rec = A.big[r];
+                for (long long i = rec.s + tid_g; i <= rec.e; i += nthreads) u[i] = rec.x;
+            }
+            big_done = nbig;
+            ok = rbl::gs_barrier(gb, &s_flag);
+            if (!ok) break;
+        }
+        mask |= __hip_atomic_load(dirty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0 && merges) atomicAdd(A.counters, merges);
+    if (!ok && threadIdx.x == 0) __hip_atomic_store((gu32*)(A.counters + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------- setup kernels
@@ -1156,29 +1369,76 @@ int launch_add_u32(int64_t n, u32* x, u32 add, hipStream_t s) {
     return RBL_OK;
 }
 
+size_t pav_bar_uints() { return (size_t)rbl::GS_UINTS; }
+int64_t pav_big_recs() { return PU_BIG_CAP; }
+int64_t pav_fpart_doubles(int64_t n) { return 2 * ((n + PB_TILE - 1) / PB_TILE) + 2; }
+
 int launch_pav_tree(int loss, int64_t n, double rho, const double* ms, const double* sa, const double* sb, double* u,
                     Prefix pa, Prefix pb, Prefix pm, const int* branch, SeamRec* recs, u32* merge_counter,
-                    hipStream_t s, const double* u0a, const double* u0b) {
-    RBL_HIP(hipMemsetAsync(merge_counter, 0, sizeof(u32), s));
+                    hipStream_t s, const double* u0a, const double* u0b, PavExtras* ex) {
+    RBL_HIP(hipMemsetAsync(merge_counter, 0, 4 * sizeof(u32), s));   // merges | dirty levels | long fills | status
     if (n <= 0) return RBL_OK;
     static const bool thread_seams = [] {
         const char* e = getenv("RBL_PAV_THREAD_SEAMS");   // one thread per seam everywhere, for comparison
         return e && e[0] == '1';
     }();
+    static const bool no_seq = [] {
+        const char* e = getenv("RBL_PAV_NO_SEQ");          // tree merges from segments of one position on (round 2), for comparison
+        return e && e[0] == '1';
+    }();
+    static const bool no_upper = [] {
+        const char* e = getenv("RBL_PAV_UPPER_PERSIST");   // =0: two launches per upper level (round 2), for comparison
+        return e && e[0] == '0';
+    }();
+    const int bflags = (thread_seams ? 0 : 1) | (no_seq ? 2 : 0);
     // levels 0 .. log2(PB_TILE): prox + in-LDS merges, one tile per workgroup
     const unsigned tiles = (unsigned)((n + PB_TILE - 1) / PB_TILE);
-    if (loss == RBL_LOSS_BCE)
-        hipLaunchKernelGGL(k_pav_bottom<0>, dim3(tiles), dim3(PV_THREADS), 0, s, ms, sa, sb, branch, rho, (long long)n, u,
-                           merge_counter, u0a, u0b, thread_seams ? 0 : 1);
-    else
-        hipLaunchKernelGGL(k_pav_bottom<1>, dim3(tiles), dim3(PV_THREADS), 0, s, ms, sa, sb, branch, rho, (long long)n, u,
-                           merge_counter, u0a, u0b, thread_seams ? 0 : 1);
-    // upper levels: one WAVE per seam (64-ary inner searches), pooled ranges written by a fill pass
+    if (ex && ex->fpart && loss == RBL_LOSS_BCE && branch) {
+        // EHRM, branch speculated (see k_pav_bottom): tree of the speculated branch + the two singleton-stage sums, the
+        // exact test, and the other branch's tree only if the test says so (a no-op launch otherwise)
+        int* br = const_cast<int*>(branch);
+        hipLaunchKernelGGL((k_pav_bottom<0, true>), dim3(tiles), dim3(PV_THREADS), 0, s, ms, sa, sb, (const int*)nullptr, rho,
+                           (long long)n, u, merge_counter, (const double*)nullptr, (const double*)nullptr, bflags, -1, ex->B,
+                           ex->spec, ex->fpart);
+        hipLaunchKernelGGL(k_ehrm_pick, dim3(1), dim3(256), 0, s, (const double*)ex->fpart, (int)tiles, -1, br);
+        hipLaunchKernelGGL((k_pav_bottom<0, false>), dim3(tiles), dim3(PV_THREADS), 0, s, ms, sa, sb, branch, rho, (long long)n, u,
+                           merge_counter, (const double*)nullptr, (const double*)nullptr, bflags, ex->spec, 0.0, 0,
+                           (double*)nullptr);
+    } else if (loss == RBL_LOSS_BCE) {
+        hipLaunchKernelGGL((k_pav_bottom<0, false>), dim3(tiles), dim3(PV_THREADS), 0, s, ms, sa, sb, branch, rho, (long long)n, u,
+                           merge_counter, u0a, u0b, bflags, -1, 0.0, 0, (double*)nullptr);
+    } else {
+        hipLaunchKernelGGL((k_pav_bottom<1, false>), dim3(tiles), dim3(PV_THREADS), 0, s, ms, sa, sb, branch, rho, (long long)n, u,
+                           merge_counter, u0a, u0b, bflags, -1, 0.0, 0, (double*)nullptr);
+    }
+    // upper levels: one WAVE per seam (64-ary inner searches)
     static const bool no_hints = [] {
         const char* e = getenv("RBL_PAV_NO_HINTS");       // cold searches every iteration, for comparison
         return e && e[0] == '1';
     }();
     SeamRec* hint_base = no_hints ? nullptr : recs + pav_level_recs(n);
+    if (ex && ex->bar && ex->big && !thread_seams && !no_upper && (long long)PB_TILE < n) {
+        // ... all of them in one persistent launch (k_pav_upper): at most one block per CU
+        PavUpperArgs A;
+        A.hints = hint_base;
+        A.big = ex->big;
+        A.counters = merge_counter;
+        A.bar = ex->bar;
+        A.parity = ex->bar_parity;
+        ex->bar_parity ^= 1;
+        A.nlevels = 0;
+        for (long long half = PB_TILE; half < n; half <<= 1) ++A.nlevels;
+        long long want = ((n + 2LL * PB_TILE - 1) / (2LL * PB_TILE) + 3) / 4;    // one wave per seam of the lowest level
+        int grid = ex->num_cu > 0 ? ex->num_cu : 64;
+        if (want < grid) grid = (int)(want < 1 ? 1 : want);
+        if (loss == RBL_LOSS_BCE)
+            hipLaunchKernelGGL(k_pav_upper<0>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, pa, pb, pm, branch, rho, A);
+        else
+            hipLaunchKernelGGL(k_pav_upper<1>, dim3(grid), dim3(PV_THREADS), 0, s, u, (long long)n, pa, pb, pm, branch, rho, A);
+        RBL_HIP(hipGetLastError());
+        return RBL_OK;
+    }
+    // ... or two launches per level (round 2): the seams of a level, then a fill pass over the pooled ranges
     int level = PB_TILE_LOG + 1;
     for (long long half = PB_TILE; half < n; half <<= 1, ++level) {
         const long long nseams = (n + 2 * half - 1) / (2 * half);

@@ -113,6 +113,21 @@ size_t sort_ghist_bytes();
 int launch_radix_sort(SortWorkspace& ws, int64_t n, bool with_vals, hipStream_t s, int key_bits = 64);
 
 // ---- pav.hip ----------------------------------------------------------------------------
+// ex (round 3, optional): the upper levels in one persistent launch (bar / big / num_cu) and, for a single-handle EHRM
+// z-step, the branch speculated from the previous iteration with the singleton-stage sums formed inside the bottom
+// kernel (fpart / spec / B; `branch` is then WRITTEN by the exact test before the upper levels read it).
+struct PavExtras {
+    unsigned* bar;      // pav_bar_uints() counters, zeroed at allocation
+    int bar_parity;     // flips per launch
+    SeamRec* big;       // pav_big_recs() entries: long pooled ranges all blocks fill together
+    int num_cu;
+    double* fpart;      // pav_fpart_doubles(n): per-tile shares of the two sums (NULL: no speculation)
+    int spec;           // speculated branch (0 = a, 1 = b)
+    double B;
+};
+size_t pav_bar_uints();
+int64_t pav_big_recs();
+int64_t pav_fpart_doubles(int64_t n);
 struct PavWorkspace {
     double* ms;        // n   sorted m
     double* u;         // n   current block values by sorted position
@@ -121,9 +136,10 @@ struct PavWorkspace {
     double* cph_m;     // nchunks
     double* cpl_m;     // nchunks
     SeamRec* recs;     // seams of the upper levels
-    u32* counters;     // [0] merges
+    u32* counters;     // [0] merges, [1] dirty upper levels, [2] long fills, [3] status of the persistent upper-level kernel
     double* partials;  // reduce scratch
     int* branch;       // EHRM branch flag on the device (0 = a, 1 = b)
+    PavExtras ex;      // round-3 paths of launch_pav_tree (buffers owned by this workspace)
 };
 int64_t pav_num_chunks(int64_t n);
 int64_t pav_num_recs(int64_t n);
@@ -142,7 +158,7 @@ int launch_ehrm_branch(int64_t n, const double* sa, const double* sb, double B, 
 // u0a / u0b != NULL: level 0 (element prox of branch a / b) was computed already; u0a may alias u
 int launch_pav_tree(int loss, int64_t n, double rho, const double* ms, const double* sa, const double* sb, double* u,
                     Prefix pa, Prefix pb, Prefix pm, const int* branch, SeamRec* recs, u32* merge_counter,
-                    hipStream_t s, const double* u0a = nullptr, const double* u0b = nullptr);
+                    hipStream_t s, const double* u0a = nullptr, const double* u0b = nullptr, PavExtras* ex = nullptr);
 // z[perm[i]] = clip(u[i]); c[perm[i]] = z + lam[perm[i]]/rho  (local slice [off, off+nloc))
 // ---- distributed z-step (merge tree over ranks; pav.hip, CPU restatement oracle/zdist.py)
 struct ZdSeam {
@@ -257,8 +273,8 @@ int launch_gram(int storage, const void* D, int64_t n, int64_t ld, int64_t d, do
 
 // ---- synth.hip --------------------------------------------------------------------------
 int launch_synth(int storage, void* D, int64_t n, int64_t ld, int64_t d, int64_t row_offset, u64 seed,
-                 double class_sep, double flip_y, const int* colperm, const double* mix, signed char* ysign,
-                 hipStream_t s);
+                 double class_sep, double flip_y, const int* special, const double* mix, const double* A16,
+                 const int* vertex, signed char* ysign, hipStream_t s);
 
 // ---- zband.hip: z-step for piecewise-constant rank weights without a sort -------------------
 constexpr int ZB_BITS = 11;          // radix-select digit (last pass: the remaining 9 bits)

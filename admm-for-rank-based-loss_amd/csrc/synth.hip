@@ -2,7 +2,9 @@
 // host (BASELINE configs C2-C5 do not fit host-side generation + upload).  Reproduces the
 // STATISTICS of the reference's synthetic branch, src/util/load_data.py:101-116
 // (sklearn make_classification defaults: 2 informative + 2 redundant columns, the other
-// d-4 columns N(0,1) noise, 2 clusters per class on hypercube vertices, class_sep,
+// d-4 columns N(0,1) noise, 2 clusters per class on hypercube vertices - cluster k belongs to
+// class k % 2, its points are standard normal draws times a random matrix A_k with entries
+// uniform in (-1, 1), shifted to its vertex at +-class_sep -, redundant = informative @ B,
 // flip_y label noise, shuffled columns) followed by preprocessing.scale (done by
 // launch_colstats + launch_standardize_negy in sweep.hip).  Counter-based Philox4x32-10,
 // keyed by the seed and indexed by (global row, column packet): any sharding of the rows
@@ -48,6 +50,8 @@ struct SynthParams {
     float class_sep, flip_y;
     int special[4];   // output columns that hold the 2 informative + 2 redundant features
     float mix[4];     // redundant = informative @ mix (2 x 2)
+    float A[4][4];    // cluster k: informative = (g0, g1) @ A_k (2 x 2, row-major) + centroid_k
+    float cen[4][2];  // centroid of cluster k: its hypercube vertex at +-class_sep
 };
 
 template <typename T>
@@ -74,8 +78,9 @@ __global__ __launch_bounds__(256) void k_synth(T* __restrict__ D, SynthParams P,
         if (touches) {
             float g0, g1;
             box_muller(rr.z, rr.w, g0, g1);
-            const float f0 = g0 + P.class_sep * (y01 ? 1.0f : -1.0f);  // informative 0: separates the classes
-            const float f1 = g1 + P.class_sep * (cl ? 1.0f : -1.0f);   // informative 1: the two clusters
+            const int c = (cl << 1) | y01;                             // cluster: class = c % 2 as in make_classification
+            const float f0 = g0 * P.A[c][0] + g1 * P.A[c][2] + P.cen[c][0];
+            const float f1 = g0 * P.A[c][1] + g1 * P.A[c][3] + P.cen[c][1];
             const float feat[4] = {f0, f1, f0 * P.mix[0] + f1 * P.mix[2], f0 * P.mix[1] + f1 * P.mix[3]};
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -91,8 +96,8 @@ __global__ __launch_bounds__(256) void k_synth(T* __restrict__ D, SynthParams P,
 }  // namespace
 
 int launch_synth(int storage, void* D, int64_t n, int64_t ld, int64_t d, int64_t row_offset, u64 seed,
-                 double class_sep, double flip_y, const int* special, const double* mix, signed char* ysign,
-                 hipStream_t s) {
+                 double class_sep, double flip_y, const int* special, const double* mix, const double* A16,
+                 const int* vertex, signed char* ysign, hipStream_t s) {
     SynthParams P;
     P.n = n;
     P.ld = ld;
@@ -105,6 +110,9 @@ int launch_synth(int storage, void* D, int64_t n, int64_t ld, int64_t d, int64_t
     for (int k = 0; k < 4; ++k) {
         P.special[k] = special[k];
         P.mix[k] = (float)mix[k];
+        for (int j = 0; j < 4; ++j) P.A[k][j] = (float)A16[4 * k + j];
+        P.cen[k][0] = (float)class_sep * ((vertex[k] & 1) ? 1.0f : -1.0f);
+        P.cen[k][1] = (float)class_sep * ((vertex[k] & 2) ? 1.0f : -1.0f);
     }
     long long total = n * (ld / 4);
     if (total <= 0) return RBL_OK;

@@ -45,8 +45,10 @@ def _box_muller(a, b):
 
 
 def special_columns(seed, d):
-    """positions of the 2 informative + 2 redundant columns and the 2x2 mixing matrix: the host-side LCG of
-    api.hip: rbl_synth_local (identical on every rank)"""
+    """positions of the 2 informative + 2 redundant columns, the 2x2 mixing matrix, the four clusters' 2x2
+    covariance matrices A_k (row-major) and the hypercube vertex of each cluster (bit 0 / bit 1 = sign of the first /
+    second informative coordinate; cluster k belongs to class k % 2, as in make_classification): the host-side LCG
+    of api.hip: rbl_synth_local (identical on every rank)"""
     m64 = (1 << 64) - 1
     st = (seed * 6364136223846793005 + 1442695040888963407) & m64
 
@@ -63,7 +65,12 @@ def special_columns(seed, d):
                 special[k] = c
                 break
     mix = [2.0 * (nxt() / 2147483648.0) - 1.0 for _ in range(4)]
-    return special, np.array(mix, dtype=np.float32)
+    A = [2.0 * (nxt() / 2147483648.0) - 1.0 for _ in range(16)]
+    vertex = [0, 1, 2, 3]
+    for i in range(3, 0, -1):
+        j = nxt() % (i + 1)
+        vertex[i], vertex[j] = vertex[j], vertex[i]
+    return special, np.array(mix, dtype=np.float32), np.array(A, dtype=np.float32).reshape(4, 4), vertex
 
 
 def raw_rows(seed, d, row_lo, row_hi, class_sep=1.0, flip_y=0.01):
@@ -86,11 +93,15 @@ def raw_rows(seed, d, row_lo, row_hi, class_sep=1.0, flip_y=0.01):
     y01 = (q0 & np.uint32(1)).astype(np.int64)
     cl = ((q0 >> np.uint32(1)) & np.uint32(1)).astype(np.int64)
     ylab = np.where(_u01(q1) < np.float32(flip_y), ((q0 >> np.uint32(2)) & np.uint32(1)).astype(np.int64), y01)
-    special, mix = special_columns(seed, d)
+    special, mix, A, vertex = special_columns(seed, d)
     g0, g1 = _box_muller(q2, q3)
     cs = np.float32(class_sep)
-    f0 = g0 + cs * np.where(y01 == 1, np.float32(1), np.float32(-1))
-    f1 = g1 + cs * np.where(cl == 1, np.float32(1), np.float32(-1))
+    c = (cl << 1) | y01                                    # cluster: class = c % 2
+    vx = np.array(vertex)
+    cen0 = cs * np.where(vx[c] & 1, np.float32(1), np.float32(-1)).astype(np.float32)
+    cen1 = cs * np.where(vx[c] & 2, np.float32(1), np.float32(-1)).astype(np.float32)
+    f0 = (g0 * A[c, 0] + g1 * A[c, 2] + cen0).astype(np.float32)
+    f1 = (g0 * A[c, 1] + g1 * A[c, 3] + cen1).astype(np.float32)
     feat = [f0, f1, (f0 * mix[0] + f1 * mix[2]).astype(np.float32), (f0 * mix[1] + f1 * mix[3]).astype(np.float32)]
     for k in range(4):
         if special[k] >= 0:

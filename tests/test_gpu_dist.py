@@ -41,12 +41,13 @@ def _run(rank, world, port, cfg, out):
         os.environ["RBL_NO_ZBAND"] = "1"          # the single-handle reference run: sort + merge-tree PAV z-step
     if world > 1:
         os.environ.update(cfg.get("env", {}))     # only the sharded run: the single-handle run stays the plain path
-        # This rig puts `world` processes on ONE GPU next to the test runner's own context.  With the HIP default of
-        # four hardware queues per process the device's queue slots are oversubscribed, and small problems (a
-        # collective every few microseconds) then stall for good in a device wait of one rank (seen with 4 ranks of
-        # n = 5 / n = 64 after in-process GPU tests; every rank on one queue: clean).  One process per GPU - the real
-        # deployment - never gets there.
-        if os.environ.get("RBL_TEST_QUEUE_LIMIT", "1") != "0":
+        # Round 2 saw the 4-rank n = 5 / n = 64 cases stall for good: rank 1 spinning in a host<->device copy of a staged
+        # gather while rank 2 spun inside gloo's all-reduce of a DEVICE tensor (gloo copies such a tensor on streams of
+        # its own) and the other ranks waited for them on the network (gpurun_out/dbgD.log).  ShardedADMM._allreduce
+        # was the one collective that still handed gloo a device tensor; it stages through the host now like the
+        # gathers and the all-to-alls, and the suite runs with HIP's default queue count again (round 2's rig forced
+        # GPU_MAX_HW_QUEUES=1, which only hid it).  RBL_TEST_QUEUE_LIMIT=1 restores that setting for comparisons.
+        if os.environ.get("RBL_TEST_QUEUE_LIMIT", "0") == "1":
             os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
     import torch
     import torch.distributed as dist
@@ -61,7 +62,7 @@ def _run(rank, world, port, cfg, out):
         s = rbl.Solver(cnt, cfg["d"], cfg["wf"], cfg["loss"], reg=cfg["reg"], wstep=cfg["wstep"], B=cfg.get("B"),
                        args=cfg.get("args"), n_total=cfg["n"], row_offset=lo, tol=0.0, storage=cfg.get("storage", "f64"))
         drv = ShardedADMM(GpuEngine(s, 0), dist_z=cfg.get("dist_z", True))
-        drv.setup_synthetic(seed=11)
+        drv.setup_synthetic(seed=12)
         drv.setup_gram()
         hist, flags = [], []
         for _ in range(cfg["iters"]):
@@ -301,7 +302,7 @@ def _thread_rank(rank, world, cfg, hub, out, errs):
         s = rbl.Solver(cnt, cfg["d"], cfg["wf"], cfg["loss"], reg=cfg["reg"], wstep=cfg["wstep"], B=cfg.get("B"),
                        args=cfg.get("args"), n_total=cfg["n"], row_offset=lo, tol=0.0, storage=cfg.get("storage", "f64"))
         drv = _make_thread_driver(ShardedADMM, hub)(GpuEngine(s, 0), world=world, rank=rank)
-        drv.setup_synthetic(seed=11)
+        drv.setup_synthetic(seed=12)
         drv.setup_gram()
         hist, flags = [], []
         for _ in range(cfg["iters"]):

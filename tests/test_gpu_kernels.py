@@ -165,6 +165,15 @@ def test_pav_large_and_pathological(L):
         u, merges = L.k_pav(loss, sa, rho, m)
         ref, nb = pav.pav_exact(loss, sa, rho, m)
         assert np.max(np.abs(u - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref))), (fam, loss, rho)
+    # EHRM at the same size: the CPT weights pool short blocks all over the upper part of the order (the sequential
+    # bottom step), long ones at small rho (cooperative fills of the one-launch upper levels), both branches
+    sa, sb = weights.get_weights("ehrm", n)
+    for rho, shift in ((1e-4, 0.0), (3e-4, -6.0), (2e-6, 0.0)):
+        m = np.sort(2 * rng.standard_normal(n) + shift)
+        z, br = L.k_pav_ehrm(sa, sb, -5.0, rho, m)
+        zo, bo = pav.ehrm_exact(sa, sb, -5.0, rho, m)
+        assert br == (0 if bo == "a" else 1), (rho, shift)
+        assert np.max(np.abs(z - zo)) <= 1e-9 * max(1.0, np.max(np.abs(zo))), (rho, shift)
     # all-equal m with increasing sigma pools everything into one block
     n = 5000
     u, _ = L.k_pav("binary_cross_entropy", np.linspace(0, 1, n), 1e-2, np.zeros(n))
@@ -180,8 +189,15 @@ def test_pav_large_and_pathological(L):
         assert u.shape == (nn,) and np.all(np.diff(u) >= 0)
 
 
-def test_pav_ehrm_golden_g3(L):
+@pytest.mark.parametrize("spec", [None, "0", "-1"], ids=["speculate_b", "speculate_a", "separate_test"])
+def test_pav_ehrm_golden_g3(L, spec, monkeypatch):
+    """EHRM z-step on sorted m against the reference's own outputs and the oracle; the automatic branch choice runs with
+    branch b speculated (the default: the tree of b and the singleton-stage sums in one kernel, the other tree only when
+    the exact test contradicts), with branch a speculated (so that the cases whose answer is b take the fall-back), and
+    through round 2's separate test kernel (RBL_EHRM_SPEC=-1)."""
     from oracle import pav
+    if spec is not None:
+        monkeypatch.setenv("RBL_EHRM_SPEC", spec)
     g = load_golden("g3_pav_cpt.npz")
     for k in range(int(g["ncases"])):
         rho, B, shift = g[f"c{k}_meta"]
