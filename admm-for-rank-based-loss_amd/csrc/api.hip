@@ -103,6 +103,17 @@ struct rbl_solver {
     bool fused_v_ran = false;
     int eig_sweeps = 0;    // Jacobi sweeps of the one-time eigendecomposition of G (l2 w-step), 0 = CG is used
     bool keys_ready = false;   // rbl_phase_m left the sort's input (keys of m, global row ids) in sw.keys[0] / vals[0]
+    // z-step with 32-bit sort keys (round 3; elementwise.hip: k_keys32 / k_sort32_fix): rbl_phase_m left m and its range
+    // (m32_ready); the sort's verdict - no run of equal keys too long to repair - arrives in pinned memory like the
+    // sort-free z-step's and is settled by the same entries (zb_resolve): not certified = redone with 64-bit keys
+    struct {
+        bool enabled = false, m_ready = false, used = false, q_done = false;
+        u64* mm = nullptr;       // range of m (device)
+        int* flag = nullptr;     // device: 1 = a run too long
+        int* pin = nullptr;      // pinned: [0] sequence number (written last), [1] flag
+        int seq = 0;
+        int64_t skip_until = 0;
+    } s32;
     int sort_passes = 0;   // radix passes executed by the z-step in flight
     // z-step without a sort for piecewise-constant rank weights (zband.hip); `used`: this iteration's z came from it
     // and its status word has not been looked at yet
@@ -220,6 +231,7 @@ int alloc_pav(PavWorkspace& pw, int64_t n) {
     RBL_TRY(dev_alloc(&pw.recs, (size_t)pav_num_recs(n)));
     RBL_HIP(hipMemset(pw.recs, 0xff, sizeof(SeamRec) * (size_t)pav_num_recs(n)));   // s = -1: no hint from a previous iteration
     RBL_TRY(dev_alloc(&pw.counters, 4));
+    RBL_HIP(hipMemset(pw.counters, 0, 4 * sizeof(u32)));   // (read by every iteration's statistics, also when the caller supplied z)
     RBL_TRY(dev_alloc(&pw.partials, (size_t)reduce_blocks() * 4));
     RBL_TRY(dev_alloc(&pw.branch, 1));
     pw.ex = PavExtras{};
@@ -369,15 +381,47 @@ int ensure_v(rbl_solver* h) {
     return RBL_OK;
 }
 
+// written by one thread behind the 32-bit sort's fix-up: its verdict for the host (sequence number last)
+static __global__ void k_publish_flag(const int* __restrict__ flag, int* __restrict__ pin, int seq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    pin[1] = flag[0];
+    __threadfence_system();
+    reinterpret_cast<volatile int*>(pin)[0] = seq;
+}
+
 // Sorted-path z-step over the n_total values in msrc (device), writing the local slice.
-int z_step_sorted(rbl_solver* h, const double* msrc, double rho) {
+// allow32: the 32-bit-key sort may be used when rbl_phase_m prepared it (h->s32.m_ready) - its verdict is settled later
+// (zb_resolve); false: 64-bit keys (the redo of an uncertified step, gathered m of the replicated distributed form).
+int z_step_sorted(rbl_solver* h, const double* msrc, double rho, bool allow32 = true) {
     hipStream_t s = h->stream;
     const int64_t nt = h->nt;
-    // rbl_phase_m already formed the keys with m when it covers the whole problem (one pass instead of two)
-    if (!(h->keys_ready && msrc == h->m && nt == h->n)) RBL_TRY(launch_keys_from_m(nt, msrc, h->sw.keys[0], h->sw.vals[0], s));
+    const u32* perm = h->sw.vals[0];
+    const bool use32 = allow32 && h->s32.m_ready && msrc == h->m && nt == h->n;
+    h->s32.m_ready = false;
+    if (use32) {
+        // fixed-point 32-bit keys of m: 4 radix passes over 8 bytes per row instead of 8 over 12, then one pass that gathers
+        // the sorted m through the row ids and repairs the short runs the 32 bits cannot tell apart
+        u32* k32 = reinterpret_cast<u32*>(h->sw.keys[0]);
+        RBL_TRY(launch_keys32(nt, h->m, h->s32.mm, k32, h->sw.vals[0], (u32)h->off, s));
+        RBL_TRY(launch_radix_sort32(h->sw, nt, s));
+        RBL_TRY(launch_sort32_fix(nt, k32, h->sw.vals[0], h->m, (u32)h->off, h->pw.ms, h->sw.vals[1], h->s32.flag, s));
+        h->s32.seq = (h->s32.seq & 0x3fffffff) + 1;
+        h->s32.pin[0] = 0;
+        hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(64), 0, s, (const int*)h->s32.flag, h->s32.pin, h->s32.seq);
+        RBL_HIP(hipGetLastError());
+        h->s32.used = true;
+        h->s32.q_done = false;
+        RBL_TRY(launch_prefix(h->pw.ms, nt, h->pw.locx_m, h->pw.chunk_m, h->pw.cph_m, h->pw.cpl_m, s));
+        perm = h->sw.vals[1];
+        h->sort_passes += 4;
+    } else {
+        // rbl_phase_m already formed the keys with m when it covers the whole problem (one pass instead of two)
+        if (!(h->keys_ready && msrc == h->m && nt == h->n)) RBL_TRY(launch_keys_from_m(nt, msrc, h->sw.keys[0], h->sw.vals[0], s));
+        RBL_TRY(launch_radix_sort(h->sw, nt, true, s));
+        RBL_TRY(launch_unflip_prefix(h->sw.keys[0], nt, h->pw.ms, h->pw.locx_m, h->pw.chunk_m, h->pw.cph_m, h->pw.cpl_m, s));
+        h->sort_passes += 8;
+    }
     h->keys_ready = false;   // the sort consumes its input
-    RBL_TRY(launch_radix_sort(h->sw, nt, true, s));
-    RBL_TRY(launch_unflip_prefix(h->sw.keys[0], nt, h->pw.ms, h->pw.locx_m, h->pw.chunk_m, h->pw.cph_m, h->pw.cpl_m, s));
     const bool ehrm = h->cfg.weight_function == RBL_W_EHRM;
     // EHRM: the branch of the previous iteration is speculated and the exact test rides on the bottom kernel
     // (pav.hip: k_pav_bottom<0, true>).  RBL_EHRM_SPEC=0 / 1: the first speculation (tests force a wrong one);
@@ -402,7 +446,7 @@ int z_step_sorted(rbl_solver* h, const double* msrc, double rho) {
     RBL_TRY(launch_pav_tree(h->cfg.loss, nt, rho, h->pw.ms, h->sigma_a, h->sigma_b, h->pw.u, h->pa, h->pb, h->pm,
                             ehrm ? h->pw.branch : nullptr, h->pw.recs, h->pw.counters, s, u0a, u0b, &ex));
     h->pw.ex.bar_parity = ex.bar_parity;
-    RBL_TRY(launch_scatter_z(nt, h->pw.u, h->sw.vals[0], ehrm ? h->pw.branch : nullptr, h->cfg.B, ehrm ? 1 : 0, rho,
+    RBL_TRY(launch_scatter_z(nt, h->pw.u, perm, ehrm ? h->pw.branch : nullptr, h->cfg.B, ehrm ? 1 : 0, rho,
                              h->lam, h->z, nullptr, h->off, h->n, s));
     return RBL_OK;
 }
@@ -538,6 +582,9 @@ int rbl_destroy(rbl_solver* h) {
     free_pav(h->pw);
     dev_free(h->zb.st); dev_free(h->zb.hist); dev_free(h->zb.part); dev_free(h->zb.tot); dev_free(h->zb.pack);
     if (h->zb.pin) (void)hipHostFree(h->zb.pin);
+    if (h->s32.pin) (void)hipHostFree(h->s32.pin);
+    dev_free(h->s32.mm);
+    dev_free(h->s32.flag);
     dev_free(h->locx_a); dev_free(h->chunk_a); dev_free(h->cph_a); dev_free(h->cpl_a);
     dev_free(h->locx_b); dev_free(h->chunk_b); dev_free(h->cph_b); dev_free(h->cpl_b);
     free_wstep(h->ww);
@@ -652,6 +699,14 @@ int rbl_create(const rbl_config* cfg, rbl_solver** out) {
             CK(alloc_sort(h->sw, nt, !cfg->objective_only));
             if (!cfg->objective_only) {
                 CK(alloc_pav(h->pw, nt));
+                CK(dev_alloc(&h->s32.mm, 2));
+                CK(dev_alloc(&h->s32.flag, 1));
+                CKH(hipHostMalloc((void**)&h->s32.pin, 64, hipHostMallocDefault));
+                for (int i = 0; i < 16; ++i) h->s32.pin[i] = 0;
+                {
+                    const char* e = getenv("RBL_SORT32");     // =0: 64-bit keys always (round 2), for comparison
+                    h->s32.enabled = !(e && e[0] == '0');
+                }
                 CK(alloc_prefix(&h->locx_a, &h->chunk_a, &h->cph_a, &h->cpl_a, nt));
                 if (cfg->weight_function == RBL_W_EHRM)
                     CK(alloc_prefix(&h->locx_b, &h->chunk_b, &h->cph_b, &h->cpl_b, nt));
@@ -715,6 +770,31 @@ fail:
 // *redone (optional): tells rbl_phase_w that its w-step has to be repeated.
 int zb_resolve(rbl_solver* h, bool* redone = nullptr) {
     if (redone) *redone = false;
+    if (h->s32.used) {
+        // z-step with 32-bit sort keys: a run of equal keys too long for the fix-up (many m within range / 2^32 of each
+        // other: ties on a grid, a degenerate range) - redo this iteration's z-step (and q) with 64-bit keys, and stay on
+        // them for the next 64 iterations
+        h->s32.used = false;
+        volatile int* pin = h->s32.pin;
+        if (pin[0] != h->s32.seq) rbl_spin_wait(pin, 0, h->stream);
+        if (pin[0] != h->s32.seq) {
+            rbl_set_error("z-step: the verdict of the 32-bit sort was never written");
+            (void)hipGetLastError();
+            return RBL_ERR_HIP;
+        }
+        if (pin[1] != 0) {
+            h->s32.skip_until = h->iter + 1 + 64;
+            const bool q_done = h->s32.q_done;
+            h->s32.q_done = false;
+            RBL_TRY(z_step_sorted(h, h->m, h->step_rho, false));
+            if (q_done) {
+                RBL_TRY(launch_make_c(h->n, h->z, h->lam, h->step_rho, h->c, h->stream));
+                RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream));
+            }
+            if (redone) *redone = true;
+        }
+        return RBL_OK;
+    }
     if (!h->zb.used) return RBL_OK;
     h->zb.used = false;
     volatile int* pin = h->zb.pin;
@@ -739,7 +819,7 @@ int zb_resolve(rbl_solver* h, bool* redone = nullptr) {
                           (long long)h->iter, (int)pin[1]);
     const bool q_done = h->zb.q_done;
     h->zb.c_ready = h->zb.q_done = false;
-    RBL_TRY(z_step_sorted(h, h->m, h->step_rho));
+    RBL_TRY(z_step_sorted(h, h->m, h->step_rho, false));
     if (q_done) {
         RBL_TRY(launch_make_c(h->n, h->z, h->lam, h->step_rho, h->c, h->stream));
         RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream));
@@ -1116,11 +1196,25 @@ int rbl_phase_m(rbl_solver* h) {
     if (h->fused_ok && h->z_ready) return RBL_OK;
     RBL_TRY(ensure_v(h));
     if (h->sorted_path) {
-        // m = D w - lambda/rho (algorithms.py:89) and, in the same pass, the sort's input for the z-step: keys of
-        // m with the GLOBAL row id as payload (single GPU: off = 0; sharded: what rbl_zd_sort_local sorts)
-        RBL_TRY(launch_make_m_keys(h->n, h->step_rho, h->v, h->lam, h->m, h->sw.keys[0], h->sw.vals[0], (u32)h->off,
-                                   h->stream));
-        h->keys_ready = true;
+        if (!h->zb.checked) RBL_TRY(zb_setup(h));
+        // which z-step will follow on a single handle: the sort-free one (banded weights), else the sort - with 32-bit
+        // keys from the second iteration on (iteration 0 starts from equal m: one run) unless a step was not certified
+        const bool banded_next = h->zb.enabled && h->nt == h->n && h->iter > 0 && h->iter >= h->zb.skip_until;
+        const bool s32 = h->s32.enabled && h->s32.pin && h->nt == h->n && h->n >= 2 && h->iter > 0 &&
+                         h->iter >= h->s32.skip_until && !banded_next;
+        h->s32.m_ready = false;
+        if (s32) {
+            // m = D w - lambda/rho (algorithms.py:89) and its range (the 32-bit keys are a fixed-point image on it)
+            RBL_TRY(launch_make_m_range(h->n, h->step_rho, h->v, h->lam, h->m, h->s32.mm, h->stream));
+            h->s32.m_ready = true;
+            h->keys_ready = false;
+        } else {
+            // m and, in the same pass, the 64-bit sort's input for the z-step: keys of m with the GLOBAL row id as
+            // payload (single GPU: off = 0; sharded: what rbl_zd_sort_local sorts)
+            RBL_TRY(launch_make_m_keys(h->n, h->step_rho, h->v, h->lam, h->m, h->sw.keys[0], h->sw.vals[0], (u32)h->off,
+                                       h->stream));
+            h->keys_ready = true;
+        }
     }
     return RBL_OK;
 }
@@ -1178,6 +1272,7 @@ int rbl_phase_z_external(rbl_solver* h, const double* z) {
     h->z_ready = false;
     h->keys_ready = false;
     h->zb.used = h->zb.c_ready = false;   // whatever the library's own z-step left behind is void
+    h->s32.used = h->s32.m_ready = false;
     h->zb.mode = 0;
     if (!h->sorted_path) {
         RBL_TRY(launch_make_c(h->n, h->z, h->lam, h->step_rho, h->c, h->stream));
@@ -1225,6 +1320,7 @@ int rbl_phase_q(rbl_solver* h) {
         if (h->sorted_path && !h->zb.c_ready) RBL_TRY(launch_make_c(h->n, h->z, h->lam, h->step_rho, h->c, h->stream));
         h->zb.c_ready = false;
         h->zb.q_done = h->zb.used;   // q of an unsettled sort-free z-step (zb_resolve redoes it with the z-step)
+        h->s32.q_done = h->s32.used; // ... and of an unsettled 32-bit sort
         RBL_TRY(launch_gemvt(h->storage, h->D, h->n, h->ld, h->c, h->slab, h->q, h->num_cu, h->stream,
                              prof_now(h) ? h->kev[3] : nullptr));
         if (prof_now(h)) h->kev_pending[1] = h->n > 0;

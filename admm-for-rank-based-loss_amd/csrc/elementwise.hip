@@ -49,6 +49,88 @@ __global__ void k_make_m_keys(long long n, double rho, const double* __restrict_
     }
 }
 
+// m = v - lambda/rho (algorithms.py:89) and the range of m for the 32-bit sort keys: mm[0] = max over rows of the
+// COMPLEMENTED order-preserving key (its complement is the smallest key), mm[1] = the largest key; both start at 0
+// (one memset) and move by integer atomic max - order independent, bit-reproducible
+__global__ __launch_bounds__(EW_THREADS) void k_make_m_range(long long n, double rho, const double* __restrict__ v,
+                                                              const double* __restrict__ lam, double* __restrict__ m,
+                                                              u64* __restrict__ mm) {
+    u64 lo = 0ull, hi = 0ull;   // lo: max of ~key
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double x = v[i] - lam[i] / rho;
+        m[i] = x;
+        const u64 k = rbl::flip_key(x);
+        lo = (~k > lo) ? ~k : lo;
+        hi = (k > hi) ? k : hi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
+        lo = a > lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(reinterpret_cast<unsigned long long*>(mm), (unsigned long long)lo);
+        atomicMax(reinterpret_cast<unsigned long long*>(mm + 1), (unsigned long long)hi);
+    }
+}
+
+// 32-bit sort keys: the monotone fixed-point image of m on [min m, max m] (a subtraction, a multiplication by a
+// positive constant and a truncation, each non-decreasing under rounding), payload = global row id.  Rows whose m the
+// 32 bits cannot tell apart (spacing of the images: range / 2^32) come out of the stable sort in row order; k_sort32_fix
+// puts such runs in (m, row) order.  A degenerate range (all m equal, or not finite) gives every row key 0: one run of
+// n rows, which the fix-up reports - the caller then sorts 64-bit keys.
+__global__ void k_keys32(long long n, const double* __restrict__ m, const u64* __restrict__ mm, u32* __restrict__ keys,
+                         u32* __restrict__ idx, u32 idx_off) {
+    const double lo = rbl::unflip_key(~mm[0]), hi = rbl::unflip_key(mm[1]);
+    double scale = 4294967295.0 / (hi - lo);
+    if (!(hi > lo) || !(scale < 1.7e308)) scale = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double t = (m[i] - lo) * scale;
+        keys[i] = t >= 4294967295.0 ? 0xffffffffu : (t > 0.0 ? (u32)t : 0u);
+        idx[i] = (u32)i + idx_off;
+    }
+}
+
+// After the 32-bit sort: ms[p] = m of the row at sorted position p, ids_out[p] = its row id, with every run of equal
+// 32-bit keys rearranged into (m, row id) order - each element of a run counts the run's elements that precede it in
+// that order (runs are pairs, rarely triples: the images of neighbouring m differ by ~2^32 / n).  A run longer than
+// S32_MAX_RUN sets *flag; the values written for it are then meaningless and the caller redoes the z-step with 64-bit
+// keys.  (Equal m keep their row order, as in the stable 64-bit sort: SURVEY 3.4-e.)
+constexpr int S32_MAX_RUN = 32;
+__global__ void k_sort32_fix(long long n, const u32* __restrict__ keys, const u32* __restrict__ ids,
+                             const double* __restrict__ m, u32 off, double* __restrict__ ms, u32* __restrict__ ids_out,
+                             int* __restrict__ flag) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const u32 k = keys[i], id = ids[i];
+        const double x = m[id - off];
+        const bool prev = i > 0 && keys[i - 1] == k, next = i + 1 < n && keys[i + 1] == k;
+        if (!prev && !next) {
+            ms[i] = x;
+            ids_out[i] = id;
+            continue;
+        }
+        long long s0 = i, e0 = i;   // the run [s0, e0]
+        while (s0 > 0 && i - s0 < S32_MAX_RUN && keys[s0 - 1] == k) --s0;
+        while (e0 + 1 < n && e0 - i < S32_MAX_RUN && keys[e0 + 1] == k) ++e0;
+        if (e0 - s0 + 1 > S32_MAX_RUN) {
+            *flag = 1;
+            ms[i] = x;
+            ids_out[i] = id;
+            continue;
+        }
+        int rank = 0;
+        for (long long j = s0; j <= e0; ++j) {
+            if (j == i) continue;
+            const u32 idj = ids[j];
+            const double xj = m[idj - off];
+            rank += (xj < x || (xj == x && idj < id)) ? 1 : 0;
+        }
+        ms[s0 + rank] = x;
+        ids_out[s0 + rank] = id;
+    }
+}
+
 __global__ void k_keys_from_m(long long n, const double* __restrict__ m, u64* __restrict__ keys,
                               u32* __restrict__ idx) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -269,6 +351,36 @@ int launch_make_m_keys(int64_t n, double rho, const double* v, const double* lam
                        u32 idx_off, hipStream_t s) {
     if (n <= 0) return RBL_OK;
     hipLaunchKernelGGL(k_make_m_keys, dim3(ew_grid(n)), dim3(256), 0, s, (long long)n, rho, v, lam, m, keys, idx, idx_off);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_make_m_range(int64_t n, double rho, const double* v, const double* lam, double* m, u64* mm, hipStream_t s) {
+    RBL_HIP(hipMemsetAsync(mm, 0, 2 * sizeof(u64), s));
+    if (n <= 0) return RBL_OK;
+    long long g = (n + EW_THREADS - 1) / EW_THREADS;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_make_m_range, dim3((unsigned)g), dim3(EW_THREADS), 0, s, (long long)n, rho, v, lam, m, mm);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_keys32(int64_t n, const double* m, const u64* mm, u32* keys, u32* idx, u32 idx_off, hipStream_t s) {
+    if (n <= 0) return RBL_OK;
+    long long g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(k_keys32, dim3((unsigned)g), dim3(256), 0, s, (long long)n, m, mm, keys, idx, idx_off);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+int launch_sort32_fix(int64_t n, const u32* keys, const u32* ids, const double* m, u32 off, double* ms, u32* ids_out, int* flag,
+                      hipStream_t s) {
+    RBL_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
+    if (n <= 0) return RBL_OK;
+    long long g = (n + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(k_sort32_fix, dim3((unsigned)g), dim3(256), 0, s, (long long)n, keys, ids, m, off, ms, ids_out, flag);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

@@ -77,6 +77,12 @@ int launch_erm_zc(int loss, int64_t n, double sigma0, double rho, const double* 
 int launch_make_m_keys(int64_t n, double rho, const double* v, const double* lam, double* m, u64* keys, u32* idx,
                        u32 idx_off, hipStream_t s);
 int launch_keys_from_m(int64_t n, const double* m, u64* keys, u32* idx, hipStream_t s);
+// z-step with 32-bit sort keys (round 3): m and its range; the fixed-point keys; after the sort, sorted m / row ids with
+// the runs of equal keys put in (m, row) order (*flag = 1: a run too long - sort 64-bit keys instead)
+int launch_make_m_range(int64_t n, double rho, const double* v, const double* lam, double* m, u64* mm, hipStream_t s);
+int launch_keys32(int64_t n, const double* m, const u64* mm, u32* keys, u32* idx, u32 idx_off, hipStream_t s);
+int launch_sort32_fix(int64_t n, const u32* keys, const u32* ids, const double* m, u32 off, double* ms, u32* ids_out, int* flag,
+                      hipStream_t s);
 int launch_prox(int loss, int64_t n, const double* sigma, double rho, const double* m, double* out,
                 hipStream_t s);
 // lambda += rho (z - v); partial sums {sum (z-v)^2, sum loss(v)} -> red[0..1]
@@ -111,6 +117,7 @@ size_t sort_ghist_bytes();
 // sorts keys[0]/vals[0] ascending (stable); result ends in keys[0]/vals[0]
 // key_bits: number of low key bits that can differ (digits above are skipped)
 int launch_radix_sort(SortWorkspace& ws, int64_t n, bool with_vals, hipStream_t s, int key_bits = 64);
+int launch_radix_sort32(SortWorkspace& ws, int64_t n, hipStream_t s);
 
 // ---- pav.hip ----------------------------------------------------------------------------
 // ex (round 3, optional): the upper levels in one persistent launch (bar / big / num_cu) and, for a single-handle EHRM

@@ -43,10 +43,12 @@ RsPlan rs_plan(long long n) {
     return p;
 }
 
-__device__ inline u32 digit_of(u64 key, int shift) { return (u32)(key >> shift) & 0xffu; }
+template <typename K>
+__device__ inline u32 digit_of(K key, int shift) { return (u32)(key >> shift) & 0xffu; }
 
 // (1) spine[digit * G + block] = number of keys of this block's range with that digit
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64* __restrict__ keys, long long n, int shift,
+template <typename K>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const K* __restrict__ keys, long long n, int shift,
                                                          int tiles_per_block, u32* __restrict__ spine, int G) {
     __shared__ u32 h[RS_WAVES][RS_BINS];
     const int tid = threadIdx.x, wave = tid >> 6;
@@ -117,13 +119,13 @@ __global__ __launch_bounds__(1024) void k_rs_scan_rows(u32* __restrict__ spine, 
 // (3) scatter.  Wave w of the block owns keys [w*1024, (w+1)*1024) of the tile, 16 rounds
 // of 64; ranks among equal digits come from 8 ballots per round plus a per-wave running
 // count in LDS (no block barrier inside the round loop).
-template <bool HAS_VAL>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64* __restrict__ kin, const u32* __restrict__ vin,
-                                                            u64* __restrict__ kout, u32* __restrict__ vout,
+template <typename K, bool HAS_VAL>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const K* __restrict__ kin, const u32* __restrict__ vin,
+                                                            K* __restrict__ kout, u32* __restrict__ vout,
                                                             long long n, int shift, int tiles_per_block,
                                                             const u32* __restrict__ spine,
                                                             const u32* __restrict__ bin_base, int G) {
-    __shared__ u64 skey[RS_TILE];
+    __shared__ K skey[RS_TILE];
     __shared__ u32 sval[HAS_VAL ? RS_TILE : 1];
     __shared__ u32 wave_run[RS_WAVES][RS_BINS];  // running digit counts of each wave inside the tile
     __shared__ u32 tile_start[RS_BINS];          // exclusive scan of the tile's digit totals
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64* __restrict
         for (int i = tid; i < RS_WAVES * RS_BINS; i += RS_THREADS) (&wave_run[0][0])[i] = 0;
         __syncthreads();
 
-        u64 key[RS_ITEMS];
+        K key[RS_ITEMS];
         u32 val[RS_ITEMS];
         unsigned short rank[RS_ITEMS];
         volatile u32* myrun = wave_run[wave];
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64* __restrict
             const int local = wave * (RS_TILE / RS_WAVES) + r * 64 + lane;
             const long long gi = tile_base + local;
             const bool ok = local < tile_valid;
-            key[r] = ok ? kin[gi] : ~0ull;  // padding sorts behind every real key of the tile
+            key[r] = ok ? kin[gi] : (K)~(K)0;  // padding sorts behind every real key of the tile
             if (HAS_VAL) val[r] = ok ? vin[gi] : 0u;
         }
 #pragma unroll
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64* __restrict
         for (int j = 0; j < RS_ITEMS; ++j) {
             const int p = j * RS_THREADS + tid;
             if (p < tile_valid) {
-                const u64 k = skey[p];
+                const K k = skey[p];
                 const u32 dg = digit_of(k, shift);
                 const long long dst = (long long)glob_off[dg] + (p - (int)tile_start[dg]);
                 kout[dst] = k;
@@ -241,6 +243,40 @@ size_t sort_ghist_bytes() { return sizeof(u32) * 16; }   // the spine scan's don
 
 size_t sort_spine_bytes() { return sizeof(u32) * RS_BINS * RS_MAX_BLOCKS; }
 
+namespace {
+template <typename K>
+int radix_passes(SortWorkspace& ws, K* k0, K* k1, int64_t n, bool with_vals, int npass, hipStream_t s) {
+    if (n >= (1LL << 32)) {
+        rbl_set_error("radix sort: n must be < 2^32");
+        return RBL_ERR_INVALID;
+    }
+    if (!ws.ghist) {
+        rbl_set_error("radix sort: workspace without its counter block");
+        return RBL_ERR_STATE;
+    }
+    RsPlan p = rs_plan(n);
+    K* kk[2] = {k0, k1};
+    int cur = 0;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = pass * 8;
+        hipLaunchKernelGGL(k_rs_hist<K>, dim3(p.nblocks), dim3(RS_THREADS), 0, s, (const K*)kk[cur], (long long)n, shift,
+                           p.tiles_per_block, ws.spine, p.nblocks);
+        hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, s, ws.spine, p.nblocks, ws.bin_total, ws.bin_base, ws.ghist);
+        if (with_vals)
+            hipLaunchKernelGGL((k_rs_scatter<K, true>), dim3(p.nblocks), dim3(RS_THREADS), 0, s, (const K*)kk[cur],
+                               (const u32*)ws.vals[cur], kk[cur ^ 1], ws.vals[cur ^ 1], (long long)n, shift, p.tiles_per_block,
+                               (const u32*)ws.spine, (const u32*)ws.bin_base, p.nblocks);
+        else
+            hipLaunchKernelGGL((k_rs_scatter<K, false>), dim3(p.nblocks), dim3(RS_THREADS), 0, s, (const K*)kk[cur],
+                               (const u32*)nullptr, kk[cur ^ 1], (u32*)nullptr, (long long)n, shift, p.tiles_per_block,
+                               (const u32*)ws.spine, (const u32*)ws.bin_base, p.nblocks);
+        cur ^= 1;
+    }
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;  // even number of passes: the result is back in the first buffer pair
+}
+}  // namespace
+
 int launch_radix_sort(SortWorkspace& ws, int64_t n, bool with_vals, hipStream_t s, int key_bits) {
     if (n <= 1) return RBL_OK;
     // keys known to fit key_bits bits need only that many digits; an even number of passes keeps
@@ -249,33 +285,12 @@ int launch_radix_sort(SortWorkspace& ws, int64_t n, bool with_vals, hipStream_t 
     if (npass < 1) npass = 1;
     npass = (npass + 1) & ~1;
     if (npass > 8) npass = 8;
-    if (n >= (1LL << 32)) {
-        rbl_set_error("radix sort: n must be < 2^32");
-        return RBL_ERR_INVALID;
-    }
-    RsPlan p = rs_plan(n);
-    int cur = 0;
-    for (int pass = 0; pass < npass; ++pass) {
-        const int shift = pass * 8;
-        hipLaunchKernelGGL(k_rs_hist, dim3(p.nblocks), dim3(RS_THREADS), 0, s, ws.keys[cur], (long long)n, shift,
-                           p.tiles_per_block, ws.spine, p.nblocks);
-        if (ws.ghist) {
-            hipLaunchKernelGGL(k_rs_scan_rows, dim3(RS_BINS), dim3(1024), 0, s, ws.spine, p.nblocks, ws.bin_total, ws.bin_base,
-                               ws.ghist);
-        } else {
-            rbl_set_error("radix sort: workspace without its counter block");
-            return RBL_ERR_STATE;
-        }
-        if (with_vals)
-            hipLaunchKernelGGL((k_rs_scatter<true>), dim3(p.nblocks), dim3(RS_THREADS), 0, s, ws.keys[cur],
-                               ws.vals[cur], ws.keys[cur ^ 1], ws.vals[cur ^ 1], (long long)n, shift,
-                               p.tiles_per_block, ws.spine, ws.bin_base, p.nblocks);
-        else
-            hipLaunchKernelGGL((k_rs_scatter<false>), dim3(p.nblocks), dim3(RS_THREADS), 0, s, ws.keys[cur],
-                               (const u32*)nullptr, ws.keys[cur ^ 1], (u32*)nullptr, (long long)n, shift,
-                               p.tiles_per_block, ws.spine, ws.bin_base, p.nblocks);
-        cur ^= 1;
-    }
-    RBL_HIP(hipGetLastError());
-    return RBL_OK;  // even number of passes: the result is back in keys[0] / vals[0]
+    return radix_passes<u64>(ws, ws.keys[0], ws.keys[1], n, with_vals, npass, s);
+}
+
+// 32-bit keys (the first n u32 of keys[0], scratch: the first n u32 of keys[1]) with the payload in vals[0]: 4 passes
+// over 8 bytes per element instead of 8 passes over 12 (the z-step's fixed-point image of m, elementwise.hip: k_keys32)
+int launch_radix_sort32(SortWorkspace& ws, int64_t n, hipStream_t s) {
+    if (n <= 1) return RBL_OK;
+    return radix_passes<u32>(ws, reinterpret_cast<u32*>(ws.keys[0]), reinterpret_cast<u32*>(ws.keys[1]), n, true, 4, s);
 }

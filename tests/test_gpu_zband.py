@@ -165,3 +165,32 @@ def test_banded_z_step_against_the_reference_goldens(R, monkeypatch):
         assert st.zband in (0, 1, 2)
         seen += 1
     assert seen >= 2
+
+
+def test_uncertified_z_step_redo_is_bit_identical_with_the_lasso(R, monkeypatch):
+    """rbl_phase_w runs the w-step on a q formed from a z that is not certified yet; when the verdict says
+    "redo", z and q are rebuilt with the sort and the w-step runs a second time from w_k.  With the l1 w-step (the
+    active-set lasso keeps no state between calls but its warm start, which rbl_phase_w puts back) the iterates up to the
+    first CERTIFIED sort-free step must equal a run with the fast path switched off BIT FOR BIT - the redone iterations
+    (mode 2) and the pauses between them are the sort path on identical inputs."""
+    n, d, nit = 60_000, 24, 10
+
+    def run(no_zband):
+        monkeypatch.setenv("RBL_NO_ZBAND", "1" if no_zband else "0")
+        monkeypatch.setenv("RBL_ZBAND_MIN_N", "16")
+        s = R.Solver(n, d, "superquantile", "binary_cross_entropy", reg=0.01, wstep=1, args=[0.5], tol=0.0, storage="f64")
+        s.generate_synthetic(seed=5)
+        out = []
+        for _ in range(nit):
+            st = s.step(True)
+            state = s.get_state()
+            out.append((st.zband, st.primal, st.dual, st.objective, state["w"].copy(), state["z"].copy()))
+        return out
+
+    a, b = run(True), run(False)
+    modes = [o[0] for o in b]
+    first_certified = modes.index(1) if 1 in modes else nit
+    assert 2 in modes[:first_certified], modes          # at least one redone iteration was compared
+    for k in range(first_certified):
+        assert a[k][1:4] == b[k][1:4], (k, modes)
+        assert np.array_equal(a[k][4], b[k][4]) and np.array_equal(a[k][5], b[k][5]), (k, modes)
