@@ -699,7 +699,7 @@ int rbl_create(const rbl_config* cfg, rbl_solver** out) {
             CK(alloc_sort(h->sw, nt, !cfg->objective_only));
             if (!cfg->objective_only) {
                 CK(alloc_pav(h->pw, nt));
-                CK(dev_alloc(&h->s32.mm, 2));
+                CK(dev_alloc(&h->s32.mm, (size_t)s32_range_words()));
                 CK(dev_alloc(&h->s32.flag, 1));
                 CKH(hipHostMalloc((void**)&h->s32.pin, 64, hipHostMallocDefault));
                 for (int i = 0; i < 16; ++i) h->s32.pin[i] = 0;

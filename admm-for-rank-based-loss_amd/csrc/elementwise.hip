@@ -49,29 +49,41 @@ __global__ void k_make_m_keys(long long n, double rho, const double* __restrict_
     }
 }
 
-// m = v - lambda/rho (algorithms.py:89) and the range of m for the 32-bit sort keys: mm[0] = max over rows of the
-// COMPLEMENTED order-preserving key (its complement is the smallest key), mm[1] = the largest key; both start at 0
-// (one memset) and move by integer atomic max - order independent, bit-reproducible
+// m = v - lambda/rho (algorithms.py:89) and the range of m for the 32-bit sort keys: every block leaves the smallest
+// and the largest order-preserving key of its rows in mm[2 b], mm[2 b + 1] (an integer min / max: order independent);
+// k_keys32 reduces those S32_RANGE_BLOCKS pairs again in every one of its blocks.  (Atomic max on two global words
+// from every wave was tried first: 16 384 contended atomics = 380 us at 6.25 M rows.)
+constexpr int S32_RANGE_BLOCKS = 1024;
 __global__ __launch_bounds__(EW_THREADS) void k_make_m_range(long long n, double rho, const double* __restrict__ v,
                                                               const double* __restrict__ lam, double* __restrict__ m,
                                                               u64* __restrict__ mm) {
-    u64 lo = 0ull, hi = 0ull;   // lo: max of ~key
+    __shared__ u64 s_lo[EW_THREADS / 64], s_hi[EW_THREADS / 64];
+    u64 lo = ~0ull, hi = 0ull;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const double x = v[i] - lam[i] / rho;
         m[i] = x;
         const u64 k = rbl::flip_key(x);
-        lo = (~k > lo) ? ~k : lo;
-        hi = (k > hi) ? k : hi;
+        lo = k < lo ? k : lo;
+        hi = k > hi ? k : hi;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const u64 a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
-        lo = a > lo ? a : lo;
+        lo = a < lo ? a : lo;
         hi = b > hi ? b : hi;
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicMax(reinterpret_cast<unsigned long long*>(mm), (unsigned long long)lo);
-        atomicMax(reinterpret_cast<unsigned long long*>(mm + 1), (unsigned long long)hi);
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < EW_THREADS / 64; ++w) {
+            lo = s_lo[w] < lo ? s_lo[w] : lo;
+            hi = s_hi[w] > hi ? s_hi[w] : hi;
+        }
+        mm[2 * blockIdx.x] = lo;          // (a block without rows leaves the neutral pair)
+        mm[2 * blockIdx.x + 1] = hi;
     }
 }
 
@@ -80,9 +92,32 @@ __global__ __launch_bounds__(EW_THREADS) void k_make_m_range(long long n, double
 // 32 bits cannot tell apart (spacing of the images: range / 2^32) come out of the stable sort in row order; k_sort32_fix
 // puts such runs in (m, row) order.  A degenerate range (all m equal, or not finite) gives every row key 0: one run of
 // n rows, which the fix-up reports - the caller then sorts 64-bit keys.
-__global__ void k_keys32(long long n, const double* __restrict__ m, const u64* __restrict__ mm, u32* __restrict__ keys,
-                         u32* __restrict__ idx, u32 idx_off) {
-    const double lo = rbl::unflip_key(~mm[0]), hi = rbl::unflip_key(mm[1]);
+__global__ __launch_bounds__(256) void k_keys32(long long n, const double* __restrict__ m, const u64* __restrict__ mm, int nparts,
+                                                u32* __restrict__ keys, u32* __restrict__ idx, u32 idx_off) {
+    __shared__ u64 s_lo[4], s_hi[4];
+    u64 klo = ~0ull, khi = 0ull;
+    for (int p = threadIdx.x; p < nparts; p += 256) {
+        const u64 a = mm[2 * p], b = mm[2 * p + 1];
+        klo = a < klo ? a : klo;
+        khi = b > khi ? b : khi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 a = __shfl_xor(klo, off, 64), b = __shfl_xor(khi, off, 64);
+        klo = a < klo ? a : klo;
+        khi = b > khi ? b : khi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_lo[threadIdx.x >> 6] = klo;
+        s_hi[threadIdx.x >> 6] = khi;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        klo = s_lo[w] < klo ? s_lo[w] : klo;
+        khi = s_hi[w] > khi ? s_hi[w] : khi;
+    }
+    const double lo = rbl::unflip_key(klo), hi = rbl::unflip_key(khi);
     double scale = 4294967295.0 / (hi - lo);
     if (!(hi > lo) || !(scale < 1.7e308)) scale = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -355,12 +390,11 @@ int launch_make_m_keys(int64_t n, double rho, const double* v, const double* lam
     return RBL_OK;
 }
 
+int s32_range_words() { return 2 * S32_RANGE_BLOCKS; }
+
 int launch_make_m_range(int64_t n, double rho, const double* v, const double* lam, double* m, u64* mm, hipStream_t s) {
-    RBL_HIP(hipMemsetAsync(mm, 0, 2 * sizeof(u64), s));
     if (n <= 0) return RBL_OK;
-    long long g = (n + EW_THREADS - 1) / EW_THREADS;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_make_m_range, dim3((unsigned)g), dim3(EW_THREADS), 0, s, (long long)n, rho, v, lam, m, mm);
+    hipLaunchKernelGGL(k_make_m_range, dim3(S32_RANGE_BLOCKS), dim3(EW_THREADS), 0, s, (long long)n, rho, v, lam, m, mm);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }
@@ -369,7 +403,7 @@ int launch_keys32(int64_t n, const double* m, const u64* mm, u32* keys, u32* idx
     if (n <= 0) return RBL_OK;
     long long g = (n + 255) / 256;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(k_keys32, dim3((unsigned)g), dim3(256), 0, s, (long long)n, m, mm, keys, idx, idx_off);
+    hipLaunchKernelGGL(k_keys32, dim3((unsigned)g), dim3(256), 0, s, (long long)n, m, mm, S32_RANGE_BLOCKS, keys, idx, idx_off);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

@@ -79,6 +79,7 @@ int launch_make_m_keys(int64_t n, double rho, const double* v, const double* lam
 int launch_keys_from_m(int64_t n, const double* m, u64* keys, u32* idx, hipStream_t s);
 // z-step with 32-bit sort keys (round 3): m and its range; the fixed-point keys; after the sort, sorted m / row ids with
 // the runs of equal keys put in (m, row) order (*flag = 1: a run too long - sort 64-bit keys instead)
+int s32_range_words();   // u64 words of the range buffer mm
 int launch_make_m_range(int64_t n, double rho, const double* v, const double* lam, double* m, u64* mm, hipStream_t s);
 int launch_keys32(int64_t n, const double* m, const u64* mm, u32* keys, u32* idx, u32 idx_off, hipStream_t s);
 int launch_sort32_fix(int64_t n, const u32* keys, const u32* ids, const double* m, u32 off, double* ms, u32* ids_out, int* flag,

@@ -721,9 +721,24 @@ __device__ inline void wp_matvec(const double* __restrict__ G, const double* gs,
 template <bool GLDS>
 __device__ inline void wp_stage_rows(const double* __restrict__ G, double* gs, int ld, int r0, int r1) {
     if (!GLDS) return;
-    const int cnt = (r1 - r0) * ld;
-    const double* src = G + (size_t)r0 * ld;
-    for (int i = threadIdx.x; i < cnt; i += WP_THREADS) gs[i] = src[i];
+    // 128 KB per block: 16-byte loads, 8 in flight per thread (a plain element loop - one load, one wait, one LDS
+    // store - spent ~100 us here, most of the kernel; ld is a multiple of 4, so rows keep 16-byte alignment)
+    const int cnt2 = (r1 - r0) * ld / 2;
+    const double2* src = reinterpret_cast<const double2*>(G + (size_t)r0 * ld);
+    double2* dst = reinterpret_cast<double2*>(gs);
+    for (int base = 0; base < cnt2; base += 8 * WP_THREADS) {
+        double2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * WP_THREADS + (int)threadIdx.x;
+            t[u] = i < cnt2 ? src[i] : double2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * WP_THREADS + (int)threadIdx.x;
+            if (i < cnt2) dst[i] = t[u];
+        }
+    }
 }
 
 __device__ inline void wp_publish(int* pin, int done, int iters) {
