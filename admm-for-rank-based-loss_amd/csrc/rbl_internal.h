@@ -225,7 +225,7 @@ struct WstepWorkspace {
 };
 constexpr int WSTEP_BAR_UINTS = 2 * 10 * 32;
 constexpr int WSTEP_PERSIST_MAX_LD = 2048;                                  // 8 vector elements per thread of a 256-thread block
-constexpr int WSTEP_XCH_DOUBLES = 2 * (WSTEP_PERSIST_MAX_LD + 16);
+constexpr int WSTEP_XCH_DOUBLES = 2 * (WSTEP_PERSIST_MAX_LD + 16) + 16;   // (+ debug stamps at the end)
 int launch_power_iteration(const double* G, int64_t d, double* tmp1, double* tmp2, double* scal, int iters,
                            double* lambda_host, hipStream_t s);
 // lasso / smoothed-l1 by FISTA with restart, ridge by CG; w is updated in place.

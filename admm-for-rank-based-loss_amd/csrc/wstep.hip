@@ -20,6 +20,7 @@
 #include "rbl_internal.h"
 #include "device_math.h"
 #include <cstdlib>
+#include <cstdio>
 
 namespace {
 
@@ -752,8 +753,10 @@ template <bool GLDS, int PER>
 __global__ __launch_bounds__(WP_THREADS) void k_cg_persist(const double* __restrict__ G, int ld, const double* __restrict__ q,
                                                             double rho, double reg, double tol, int max_iter,
                                                             double* __restrict__ w, double* x0, double* x1, int xbytes,
-                                                            double* __restrict__ Gw_out, unsigned* bar, int parity, int* pin) {
+                                                            double* __restrict__ Gw_out, unsigned* bar, int parity, int* pin,
+                                                            long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) double wp_lds[];
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[0] = (long long)wall_clock64();
     double* xs = wp_lds;                       // ld
     double* red = wp_lds + ld;                 // 16 (block sums)
     double* ybuf = red + 16;                   // WP_RPB
@@ -770,10 +773,12 @@ __global__ __launch_bounds__(WP_THREADS) void k_cg_persist(const double* __restr
         if (j < ld) xs[j] = wj[k];
     }
     __syncthreads();
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[1] = (long long)wall_clock64();
     wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, rho, reg, ybuf);          // A w
     int iters = 0, done = 0, ok = 1;
     double rr = 0.0, thr = 0.0;
     if (!wp_exchange<PER>(b, ybuf, x0, xbytes, aj, flag)) ok = 0;
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[2] = (long long)wall_clock64();
     if (ok) {
         double acc[2] = {0.0, 0.0};
 #pragma unroll
@@ -825,6 +830,7 @@ __global__ __launch_bounds__(WP_THREADS) void k_cg_persist(const double* __restr
         ++iters;
         done = (rr <= thr || alpha == 0.0) ? 1 : 0;
     }
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[3] = (long long)wall_clock64();
     if (ok && Gw_out) {
         __syncthreads();
 #pragma unroll
@@ -846,7 +852,9 @@ __global__ __launch_bounds__(WP_THREADS) void k_cg_persist(const double* __restr
             }
         }
         __syncthreads();
+        if (dbg && threadIdx.x == 0) dbg[4] = (long long)wall_clock64();
         if (threadIdx.x == 0) wp_publish(pin, ok ? done : -2, iters);
+        if (dbg && threadIdx.x == 0) dbg[5] = (long long)wall_clock64();
     }
 }
 
@@ -1049,6 +1057,13 @@ int run_cg_persist(const WpPlan& pl, const double* G, int64_t ld, const double* 
     ws.bar_parity ^= 1;
     double* gw = want_Gw ? ws.Gy : nullptr;
     double *x0 = ws.xch, *x1 = ws.xch + WSTEP_XCH_DOUBLES / 2;
+    // RBL_WPERSIST_DEBUG=1: block 0 leaves 100 MHz wall-clock stamps (start | rows staged | first exchange | loop done |
+    // G w written | published) behind the second exchange buffer; printed to stderr after the kernel
+    static const bool dbg_on = [] {
+        const char* e = getenv("RBL_WPERSIST_DEBUG");
+        return e && e[0] == '1';
+    }();
+    long long* dbg = dbg_on ? reinterpret_cast<long long*>(ws.xch + WSTEP_XCH_DOUBLES - 8) : nullptr;
 #define RBL_CG_PERSIST(GL, PR)                                                                                           \
     do {                                                                                                                 \
         static size_t lds_set = 0; /* (one attribute call per instantiation and size, not per launch) */                 \
@@ -1057,7 +1072,7 @@ int run_cg_persist(const WpPlan& pl, const double* G, int64_t ld, const double* 
             lds_set = pl.lds_bytes;                                                                                      \
         }                                                                                                                \
         hipLaunchKernelGGL((k_cg_persist<GL, PR>), dim3(pl.nblocks), dim3(WP_THREADS), pl.lds_bytes, s, G, (int)ld, q, rho, \
-                           reg, tol, max_iter, w, x0, x1, pl.xbytes, gw, ws.bar, parity, pin);                           \
+                           reg, tol, max_iter, w, x0, x1, pl.xbytes, gw, ws.bar, parity, pin, dbg);                      \
     } while (0)
     const bool narrow = ld <= 4 * WP_THREADS;
     if (pl.glds && narrow) RBL_CG_PERSIST(true, 4);
@@ -1070,6 +1085,12 @@ int run_cg_persist(const WpPlan& pl, const double* G, int64_t ld, const double* 
     const volatile int* st = pin;
     *status = st[0];
     *iters = st[1];
+    if (dbg) {
+        long long t[6];
+        RBL_HIP(hipMemcpy(t, dbg, sizeof(t), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[rbl] k_cg_persist: %d iterations; staged %.2f us, first exchange %.2f, loop %.2f, G w %.2f, publish %.2f\n",
+                st[1], (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01);
+    }
     return RBL_OK;
 }
 
