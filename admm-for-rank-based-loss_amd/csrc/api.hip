@@ -285,6 +285,7 @@ int alloc_wstep(WstepWorkspace& ww, int64_t ld) {
     RBL_TRY(dev_alloc(&ww.bar, (size_t)WSTEP_BAR_UINTS));
     RBL_HIP(hipMemset(ww.bar, 0, sizeof(unsigned) * WSTEP_BAR_UINTS));
     RBL_TRY(dev_alloc(&ww.xch, (size_t)WSTEP_XCH_DOUBLES));
+    RBL_HIP(hipMemset(ww.xch, 0, sizeof(double) * WSTEP_XCH_DOUBLES));   // tag 0 is never used
     RBL_TRY(alloc_wstep_pin(ww));
     return RBL_OK;
 }
@@ -2520,6 +2521,7 @@ int rbl_k_wstep(int wstep, int64_t d, const double* G, const double* q, double r
     ww.bar = sc.alloc<unsigned>((size_t)WSTEP_BAR_UINTS);
     ww.xch = sc.alloc<double>((size_t)WSTEP_XCH_DOUBLES);
     SC_CHECK(ww.yk && ww.Gy && ww.wn && ww.r && ww.p && ww.scal && ww.flags && ww.bar && ww.xch);
+    RBL_HIP(hipMemsetAsync(ww.xch, 0, sizeof(double) * WSTEP_XCH_DOUBLES, sc.s));
     RBL_HIP(hipMemsetAsync(ww.bar, 0, sizeof(unsigned) * WSTEP_BAR_UINTS, sc.s));
     RBL_TRY(alloc_wstep_pin(ww));
     struct PinGuard {

@@ -512,7 +512,9 @@ __device__ inline void seam_merge(const Acc& ac, long long L0, long long seam, l
 // esrm, EHRM's CPT weights) the solution has thousands of short blocks (pairs, triples) spread over the whole upper
 // part of the order: as tree merges each of them cost one divergent seam_merge() - searches included - per wave and
 // level (k_pav_bottom 381 us at 6.25 M EHRM positions against 141 us for a superquantile problem of the same size);
-// sequentially a pair is one comparison and one block solve.
+// sequentially a pair is one comparison and one block solve.  (A second sequential stage over 64-position segments - one
+// thread per segment walking the blocks of stage 1 through a 64-bit mask - was built and measured: 32 active lanes per
+// tile cost more than the three tree levels they replace, z-step 0.87 -> 0.93 ms at 6.25 M EHRM positions; removed.)
 //
 // EHRM with a SPECULATED branch (SPEC): the singleton-stage scalar test of PAV_cpt.py:205-226 needs
 // f1 = sum phi_a(min(prox_a(m), B)) and f2 = sum phi_b(max(prox_b(m), B)) over all positions.  Round 2 computed both
@@ -638,8 +640,6 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
     u32 merges = 0;
     // Levels 1-3: sequential PAV over the thread's own PB_PER positions (see the header comment).  `starts`: bit j set
     // = position j of the segment starts a block; all positions of a block hold its value.
-    __shared__ unsigned char s_starts[PV_THREADS];       // stage 1: block starts of every thread's 8 positions
-    __shared__ unsigned long long s_starts64[PV_THREADS / 8];
     if (seq_levels) {
         const int b0 = tid * PB_PER;
         const int cnt = (int)(nt - b0 < PB_PER ? nt - b0 : PB_PER);
@@ -671,46 +671,6 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
                 cur_s = s0;
             }
         }
-        s_starts[tid] = (unsigned char)starts;
-        __syncthreads();
-        // Levels 4-6 (segments of 64 positions) the same way, one thread per segment, now over the BLOCKS stage 1
-        // left: the eight 8-bit masks of a segment are its 64-bit stack of block starts; only the value at a block's
-        // start is kept current, the other positions are filled in afterwards by everybody.
-        if (tid < PV_THREADS / 8) {
-            const int c0 = tid * 64;
-            unsigned long long in = 0ull;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) in |= (unsigned long long)s_starts[tid * 8 + j] << (8 * j);
-            const int seg_end = (int)(nt - c0 < 64 ? nt - c0 : 64);     // valid positions of this segment
-            unsigned long long st = 0ull;
-            while (in) {
-                const int s1 = __builtin_ctzll(in);
-                in &= in - 1ull;
-                const int e1 = in ? __builtin_ctzll(in) - 1 : seg_end - 1;   // end of this block
-                double x = su[c0 + s1];
-                int bs = s1;
-                while (st) {
-                    const int ps1 = 63 - __builtin_clzll(st);                // block on top of the stack
-                    if (su[c0 + ps1] <= x) break;
-                    st &= ~(1ull << ps1);
-                    bs = ps1;
-                    x = block_value<LOSS>(spa[c0 + e1 + 1] - spa[c0 + bs], spm[c0 + e1 + 1] - spm[c0 + bs], (double)(e1 + 1 - bs), rho);
-                    ++merges;
-                }
-                su[c0 + bs] = x;
-                st |= 1ull << bs;
-            }
-            s_starts64[tid] = st;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PB_PER; ++k) {
-            const int i = tid * PB_PER + k;             // (the thread's 8 positions lie in one 64-segment)
-            const unsigned long long st = s_starts64[i >> 6];
-            const int o = i & 63;
-            const unsigned long long upto = st & ((o == 63) ? ~0ull : ((2ull << o) - 1ull));
-            if (i < nt && upto) su[i] = su[(i & ~63) + (63 - __builtin_clzll(upto))];
-        }
         __syncthreads();
     }
     // Levels with short segments: the thread that merged a seam writes the pooled range itself.
@@ -720,7 +680,7 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
     constexpr int PB_COOP = 32;
     __shared__ int rec_s[PB_TILE / (2 * PB_COOP)], rec_e[PB_TILE / (2 * PB_COOP)];
     __shared__ double rec_x[PB_TILE / (2 * PB_COOP)];
-    for (int half = seq_levels ? 64 : 1; half < PB_TILE; half <<= 1) {
+    for (int half = seq_levels ? PB_PER : 1; half < PB_TILE; half <<= 1) {
         const int nseams = PB_TILE / (2 * half);
         const bool coop = half >= PB_COOP;
         if (wave_top && nseams <= PV_THREADS / 64) {

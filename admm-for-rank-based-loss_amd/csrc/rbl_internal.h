@@ -218,14 +218,15 @@ struct WstepWorkspace {
     int last_fista; // the same for FISTA; pin[6..7] = its (done, iterations)
     // persistent one-launch w-steps (wstep.hip: k_cg_persist / k_ncg_persist): two sets of barrier counters used
     // alternately (a launch clears the set of the next one), pin[4..5] / pin[8..9] = their (status, iterations)
-    unsigned* bar;
-    double* xch;    // the two exchange buffers of the matrix-vector products (one 128-byte line per block, double-buffered)
-    int bar_parity;
+    unsigned* bar;  // [0]: abort word of the persistent kernels (a block that gave up waiting)
+    double* xch;    // the two exchange buffers of the matrix-vector products: 8-byte granules {tag | 32 bits}, two per double
+    int launch_seq; // launches so far (the tags of a launch: launch_seq << 12 | exchange number)
     bool gw_valid;  // ws.Gy holds G w of the w the last run_wstep returned
 };
 constexpr int WSTEP_BAR_UINTS = 2 * 10 * 32;
 constexpr int WSTEP_PERSIST_MAX_LD = 2048;                                  // 8 vector elements per thread of a 256-thread block
-constexpr int WSTEP_XCH_DOUBLES = 2 * (WSTEP_PERSIST_MAX_LD + 16) + 16;   // (+ debug stamps at the end)
+constexpr int WSTEP_XCH_GRANULES = 2 * (WSTEP_PERSIST_MAX_LD + 16);        // granules of one exchange buffer
+constexpr int WSTEP_XCH_DOUBLES = 2 * WSTEP_XCH_GRANULES + 16;            // two buffers (+ debug stamps at the end)
 int launch_power_iteration(const double* G, int64_t d, double* tmp1, double* tmp2, double* scal, int iters,
                            double* lambda_host, hipStream_t s);
 // lasso / smoothed-l1 by FISTA with restart, ridge by CG; w is updated in place.
@@ -263,6 +264,10 @@ int launch_predict_rho(int64_t ld, const double* q, const double* p, double* p_o
 int launch_sumsq(int64_t n, const double* x, double* partials, double* out, hipStream_t s);
 // v = D w, lambda += rho (z - v), red[0] = sum (z - v)^2 in one pass (rows up to 4 / 8 passes of 64 packets)
 bool sweep_v_supported(int storage, int64_t ld);
+// q = D^T c with the single-sweep kernel's row-streaming loads (sweep_erm.hip: SE_QONLY); launch_gemvt routes to it
+bool sweep_q_supported(int storage, int64_t ld);
+int launch_sweep_q(int storage, const void* D, int64_t n, int64_t ld, const double* c, double* slab, double* q, int num_cu,
+                   hipStream_t s, hipEvent_t main_done);
 int launch_sweep_v(int storage, const void* D, int64_t n, int64_t ld, const double* w, const double* z, double* lam,
                    double* v, double rho, double* partials, double* red, int num_cu, hipStream_t s, hipEvent_t main_done);
 int launch_symv(const double* G, int64_t ld, const double* x, double* y, hipStream_t s);

@@ -459,6 +459,7 @@ int launch_gemvt(int storage, const void* D, int64_t n, int64_t ld, const double
         RBL_HIP(hipMemsetAsync(q, 0, sizeof(double) * ld, s));
         return RBL_OK;
     }
+    if (sweep_q_supported(storage, ld)) return launch_sweep_q(storage, D, n, ld, c, slab, q, num_cu, s, main_done);
     int nb = gemvt_blocks(num_cu, n);
     if (storage == RBL_STORE_F32)
         RBL_TRY((gemvt_T<float, false>((const float*)D, n, ld, c, slab, nullptr, nb, s)));

@@ -60,6 +60,12 @@ __device__ inline void opaque(u32x4 (&buf)[R][P]) {
 // only - the z-step needs the global sort and q a second pass); the other values exist for
 // tools/sweep_lab.hip (ablation timings: which phase costs what).
 constexpr int SE_VONLY = 2 | 4 | 128;   // no accumulation phase, no prox, no z' / slab output
+// q = D^T c alone (round 3; replaces k_gemvt where the row width fits): the row's coefficient is READ (c = z + lambda/rho,
+// passed in the z_old slot) instead of computed - no dot product, no wave reduction, no prox, no row-wise stores, no
+// residual sums; the same loads in the same order, the same accumulation into per-lane column sums, one slab row per
+// block.  The thread-per-column-packet k_gemvt reads the same bytes at 6.0 TB/s, this kernel at the single-sweep
+// kernel's 6.2-6.5 (buffer loads through scalar row descriptors, a whole sub-batch of rows in flight per wave).
+constexpr int SE_QONLY = 1 | 4 | 8 | 16 | 64;
 template <typename T, int LOSS, int P, int R, int S, bool WL, int EXP = 0, bool ONE = false>
 __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
     const T* __restrict__ D, long long n, long long ld, const double* __restrict__ w, const double* __restrict__ z_old,
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int PK = (int)(ld / E);
     const unsigned row_bytes = (unsigned)ld * (unsigned)sizeof(T);
-    const double rho_next = (EXP & 128) ? 1.0 : pred[0];
+    const double rho_next = (EXP & (128 | 64)) ? 1.0 : pred[0];
 
     // w: in registers, or (WL) in LDS, one copy per block, laid out [p][lane][k] so that a
     // lane's E values are contiguous - frees 2*P*E VGPRs for a second pair of row buffers
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
         const bool mine = lane < live && !(EXP & 32);
         const long long myrow = (long long)q * SR + lane;
         zo = mine ? z_old[myrow] : 0.0;
-        lm = mine ? lam[myrow] : 0.0;
+        lm = (mine && !(EXP & 64)) ? lam[myrow] : 0.0;
     };
     auto load_rows = [&](int q, int sub, u32x4 (&buf)[R][P]) {
         const int live = q == nsuper - 1 ? live_last : SR;
@@ -165,7 +171,9 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
 #pragma unroll
         for (int r = 0; r < R; ++r) myv = (lane == sub * R + r) ? dot[r] : myv;
         double c = 0.0;
-        if (lane >= sub * R && lane < sub * R + R && lane < live) {
+        if (EXP & 64) {
+            if (lane >= sub * R && lane < sub * R + R && lane < live) c = zo;    // the coefficient was read, not computed
+        } else if (lane >= sub * R && lane < sub * R + R && lane < live) {
             const double res = zo - myv;
             const double l = lm + rho * res;                       // algorithms.py:132
             s_prim += res * res;                                   // algorithms.py:135
@@ -289,6 +297,7 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
         }
         __syncthreads();
     }
+    if (EXP & 64) return;                  // q-only: no residual sums
     double sums[3] = {s_prim, 0.0, s_zz};   // slot 1: the loss sum, filled by k_loss_sum when wanted
     __shared__ double smem[3 * SE_THREADS / 64];
     rbl::block_sum<3, SE_THREADS>(sums, smem);
@@ -742,6 +751,63 @@ int launch_sweep_v(int storage, const void* D, int64_t n, int64_t ld, const doub
         RBL_TRY(launch_v_T<double>((const double*)D, n, ld, w, z, lam, v, rho, partials, grid, s));
     if (main_done) RBL_HIP(hipEventRecord(main_done, s));
     hipLaunchKernelGGL(k_finish_v, dim3(1), dim3(256), 0, s, partials, grid, red);
+    RBL_HIP(hipGetLastError());
+    return RBL_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_finish_q(const double* __restrict__ part, long long ld, double* __restrict__ q) {
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < ld; j += (long long)gridDim.x * 256) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < CR_SLICES; ++k) s += part[(long long)k * ld + j];
+        q[j] = s;
+    }
+}
+
+template <typename T>
+int launch_q_T(const T* D, long long n, long long ld, const double* c, double* slab, int grid, hipStream_t s) {
+    const long long PK = ld / Pk<T>::E;
+    const long long passes = (PK + 63) / 64;
+#define RBL_Q(P_, R_, S_)                                                                                            \
+    do {                                                                                                             \
+        hipLaunchKernelGGL((k_sweep_erm<T, 1, P_, R_, S_, false, SE_QONLY, true>), dim3(grid), dim3(SE_THREADS), 0, s, D, n,  \
+                           ld, (const double*)nullptr, c, (double*)nullptr, (double*)nullptr, (double*)nullptr, 0.0, 1.0,     \
+                           (const double*)nullptr, slab, (double*)nullptr);                                          \
+        RBL_HIP(hipGetLastError());                                                                                  \
+        return RBL_OK;                                                                                               \
+    } while (0)
+    if (passes == 1) RBL_Q(1, 8, 2);
+    if (passes == 2) RBL_Q(2, 4, 4);
+    if (passes <= 4) RBL_Q(4, 2, 8);
+    if constexpr (sizeof(T) == 8) {
+        if (passes <= 8) RBL_Q(8, 1, 8);
+    }
+#undef RBL_Q
+    return RBL_ERR_INVALID;
+}
+}  // namespace
+
+// q = D^T c through the single-sweep kernel's loads (SE_QONLY); same widths as launch_sweep_v
+bool sweep_q_supported(int storage, int64_t ld) {
+    static const bool on = [] {
+        const char* e = getenv("RBL_GEMVT_SWEEP");     // =0: k_gemvt everywhere (round 2), for comparison
+        return !(e && e[0] == '0');
+    }();
+    return on && sweep_v_supported(storage, ld);
+}
+
+int launch_sweep_q(int storage, const void* D, int64_t n, int64_t ld, const double* c, double* slab, double* q, int num_cu,
+                   hipStream_t s, hipEvent_t main_done) {
+    const int grid = sweep_erm_blocks(num_cu);
+    if (storage == RBL_STORE_F32)
+        RBL_TRY(launch_q_T<float>((const float*)D, n, ld, c, slab, grid, s));
+    else
+        RBL_TRY(launch_q_T<double>((const double*)D, n, ld, c, slab, grid, s));
+    if (main_done) RBL_HIP(hipEventRecord(main_done, s));
+    double* part = slab + (size_t)grid * ld;
+    hipLaunchKernelGGL(k_colreduce2, dim3((unsigned)((ld + 63) / 64), CR_SLICES), dim3(256), 0, s, slab, grid, (long long)ld, part);
+    hipLaunchKernelGGL(k_finish_q, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, part, (long long)ld, q);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
 }

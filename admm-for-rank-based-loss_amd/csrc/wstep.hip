@@ -621,84 +621,70 @@ namespace {
 //     (done, iterations) go to pinned host memory: one host wait per w-step.
 // rows of d <= 2048 (8 elements per thread); wider problems keep the batched path.
 constexpr int WP_THREADS = 256;
-constexpr int WP_RPB = 16;                         // rows of G per block = one 128-byte line of the exchange buffer
-constexpr int WP_BAR_STRIDE = 32;                  // one 128-byte line per counter
-constexpr int WP_BAR_SET = 10 * WP_BAR_STRIDE;     // 8 group counters | top | abort
-constexpr unsigned WP_SPIN_CAP = 1u << 24;
-constexpr int WP_AUX_SC1 = 16;                     // cache-policy bits of a gfx950 buffer access: sc1 (system-coherent, bypasses L1)
+constexpr int WP_RPB = 16;                         // rows of G per block
+constexpr unsigned WP_SPIN_CAP = 1u << 22;         // sweeps of a collecting wave before it gives up (seconds)
 
 typedef unsigned long long wp_u64 __attribute__((address_space(1)));
 typedef unsigned wp_u32 __attribute__((address_space(1)));
 
-struct WpBarrier {
-    unsigned* set;
-    unsigned ngroups, gsize, epoch;
-};
-
-__device__ inline WpBarrier wp_barrier_init(unsigned* bar, int parity) {
-    WpBarrier b;
-    b.set = bar + parity * WP_BAR_SET;
-    // the other set was used by the previous launch, which has completed: make it ready for the next one
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < WP_BAR_SET; i += WP_THREADS) bar[(parity ^ 1) * WP_BAR_SET + i] = 0u;
-    b.ngroups = gridDim.x < 8u ? gridDim.x : 8u;
-    const unsigned g = blockIdx.x % b.ngroups;
-    b.gsize = (gridDim.x - g + b.ngroups - 1) / b.ngroups;
-    b.epoch = 0;
-    return b;
-}
-
-// index of the k-th vector element a thread owns: elements come in pairs (one 16-byte sc1 load each)
+// index of the k-th vector element a thread owns (pairs of neighbours)
 __device__ inline int wp_idx(int k) { return 2 * ((k >> 1) * WP_THREADS + (int)threadIdx.x) + (k & 1); }
 
-// Publishes this block's WP_RPB results (ybuf, LDS) into line blockIdx.x of xb, waits until every block has done so
-// and returns with the whole vector in v[] (the elements this thread owns).  false = some block gave up waiting
-// (every block then returns false and the kernel drains).
+// Publishes this block's WP_RPB results (ybuf, LDS) and returns with the whole vector in v[] (the elements this thread
+// owns).  The data IS the flag (MI355X_MICROARCH.md, Guideline 16's form R2): every double travels as two 8-byte
+// granules {tag = this exchange's number | 32 bits of the value}, each written by ONE write-through (sc1) 8-byte store -
+// the block's 32 granules by one wave instruction - and every block re-reads the granules it needs with sc1 loads until
+// all of them carry this exchange's tag.  No counter, no fence, no drain: one store and one load round trip per
+// exchange (the counter form - sc1 stores, drain, hierarchical arrival counter, poll, workgroup barrier, sc1 loads -
+// measured 6.7 us per exchange, this one is bounded by the visibility of a store).  Tags are unique over the launches of
+// a handle (launch number << 12 | exchange number), so nothing has to be cleared between launches; two buffers are used
+// alternately (a block can be one exchange ahead of the slowest one, never two).  false = some block gave up waiting.
 template <int PER>
-__device__ inline bool wp_exchange(WpBarrier& b, const double* ybuf, double* xb, int xbytes, double (&v)[PER], int* lds_flag) {
+__device__ inline bool wp_exchange(unsigned tag, const double* ybuf, unsigned long long* xg, int ld, double (&v)[PER],
+                                   unsigned* abort_word) {
     __syncthreads();                                // ybuf complete
-    if (threadIdx.x < 64) {                         // wave 0 stores, drains, arrives and polls
-        if (threadIdx.x < WP_RPB) {
-            const unsigned long long bits = __builtin_bit_cast(unsigned long long, ybuf[threadIdx.x]);
-            __hip_atomic_store(((wp_u64*)xb) + (size_t)blockIdx.x * WP_RPB + threadIdx.x, bits, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);          // global_store_dwordx2 sc1: one line, one instruction
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the stores are through before the arrival below
-        if (threadIdx.x == 0) {
-            ++b.epoch;
-            const unsigned g = blockIdx.x % b.ngroups;
-            const unsigned old = __hip_atomic_fetch_add(((wp_u32*)b.set) + g * WP_BAR_STRIDE, 1u, __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-            if (old + 1 == b.epoch * b.gsize)
-                (void)__hip_atomic_fetch_add(((wp_u32*)b.set) + 8 * WP_BAR_STRIDE, 1u, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned want = b.epoch * b.ngroups;
-            unsigned spins = 0;
-            int ok = 1;
-            while (__hip_atomic_load(((wp_u32*)b.set) + 8 * WP_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
-                   want) {
-                if (++spins > WP_SPIN_CAP ||
-                    __hip_atomic_load(((wp_u32*)b.set) + 9 * WP_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    __hip_atomic_store(((wp_u32*)b.set) + 9 * WP_BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            *lds_flag = ok;
-        }
+    if (threadIdx.x < 2 * WP_RPB) {
+        const int r = (int)threadIdx.x >> 1, h = (int)threadIdx.x & 1;
+        const unsigned long long bits = __builtin_bit_cast(unsigned long long, ybuf[r]);
+        const unsigned long long half = h ? (bits >> 32) : (bits & 0xffffffffull);
+        __hip_atomic_store((wp_u64*)xg + 2 * ((size_t)blockIdx.x * WP_RPB + r) + h, ((unsigned long long)tag << 32) | half,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();                                // between the poll and EVERY load of the handed-off bytes
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, xbytes, 0x00020000);
+    unsigned lo32[PER], hi32[PER];
+    bool have[PER];
 #pragma unroll
-    for (int kk = 0; kk < PER / 2; ++kk) {
-        const int pair = kk * WP_THREADS + (int)threadIdx.x;
-        typedef unsigned v4u __attribute__((ext_vector_type(4)));
-        const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, pair * 16, 0, WP_AUX_SC1);   // out of range: zeros
-        v[2 * kk] = __builtin_bit_cast(double, ((unsigned long long)q.y << 32) | q.x);
-        v[2 * kk + 1] = __builtin_bit_cast(double, ((unsigned long long)q.w << 32) | q.z);
+    for (int k = 0; k < PER; ++k) {
+        have[k] = wp_idx(k) >= ld;                  // elements beyond the vector: nothing to wait for
+        lo32[k] = hi32[k] = 0u;
     }
-    return *lds_flag != 0;
+    bool ok = true;
+    for (unsigned spins = 0;; ++spins) {
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (have[k]) continue;
+            const int j = wp_idx(k);
+            const unsigned long long g0 = __hip_atomic_load((wp_u64*)xg + 2 * (size_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long g1 = __hip_atomic_load((wp_u64*)xg + 2 * (size_t)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag) {
+                lo32[k] = (unsigned)g0;
+                hi32[k] = (unsigned)g1;
+                have[k] = true;
+            } else {
+                all = false;
+            }
+        }
+        if (__all(all)) break;                      // wave-uniform exit
+        if (spins > WP_SPIN_CAP || __hip_atomic_load((wp_u32*)abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            __hip_atomic_store((wp_u32*)abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = false;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) v[k] = __builtin_bit_cast(double, ((unsigned long long)hi32[k] << 32) | lo32[k]);
+    return __syncthreads_and(ok ? 1 : 0) != 0;      // every wave of the block takes the same way out
 }
 
 // rows [r0, r1) of y = alpha G x + beta x -> ybuf[row - r0] (LDS; rows beyond r1 up to r0 + WP_RPB: 0); x in LDS,
@@ -752,18 +738,17 @@ __device__ inline void wp_publish(int* pin, int done, int iters) {
 template <bool GLDS, int PER>
 __global__ __launch_bounds__(WP_THREADS) void k_cg_persist(const double* __restrict__ G, int ld, const double* __restrict__ q,
                                                             double rho, double reg, double tol, int max_iter,
-                                                            double* __restrict__ w, double* x0, double* x1, int xbytes,
-                                                            double* __restrict__ Gw_out, unsigned* bar, int parity, int* pin,
-                                                            long long* dbg) {
+                                                            double* __restrict__ w, unsigned long long* x0, unsigned long long* x1,
+                                                            unsigned tag_base, double* __restrict__ Gw_out, unsigned* abort_word,
+                                                            int* pin, long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) double wp_lds[];
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[0] = (long long)wall_clock64();
     double* xs = wp_lds;                       // ld
     double* red = wp_lds + ld;                 // 16 (block sums)
     double* ybuf = red + 16;                   // WP_RPB
-    int* flag = reinterpret_cast<int*>(ybuf + WP_RPB);
     double* gs = ybuf + WP_RPB + 16;           // WP_RPB * ld
     const int r0 = blockIdx.x * WP_RPB, r1 = min(ld, r0 + WP_RPB);
-    WpBarrier b = wp_barrier_init(bar, parity);
+    unsigned xn = 0;                            // exchanges so far (the next one's tag: tag_base + xn + 1)
     wp_stage_rows<GLDS>(G, gs, ld, r0, r1);
     double wj[PER], rj[PER], pj[PER], aj[PER];
 #pragma unroll
@@ -777,7 +762,8 @@ __global__ __launch_bounds__(WP_THREADS) void k_cg_persist(const double* __restr
     wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, rho, reg, ybuf);          // A w
     int iters = 0, done = 0, ok = 1;
     double rr = 0.0, thr = 0.0;
-    if (!wp_exchange<PER>(b, ybuf, x0, xbytes, aj, flag)) ok = 0;
+    ++xn;
+    if (!wp_exchange<PER>(tag_base + xn, ybuf, x0, ld, aj, abort_word)) ok = 0;
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[2] = (long long)wall_clock64();
     if (ok) {
         double acc[2] = {0.0, 0.0};
@@ -806,7 +792,8 @@ __global__ __launch_bounds__(WP_THREADS) void k_cg_persist(const double* __restr
         }
         __syncthreads();
         wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, rho, reg, ybuf);      // A p
-        if (!wp_exchange<PER>(b, ybuf, (iters & 1) ? x0 : x1, xbytes, aj, flag)) {
+        ++xn;
+        if (!wp_exchange<PER>(tag_base + xn, ybuf, (iters & 1) ? x0 : x1, ld, aj, abort_word)) {
             ok = 0;
             break;
         }
@@ -861,17 +848,16 @@ __global__ __launch_bounds__(WP_THREADS) void k_cg_persist(const double* __restr
 // smoothed-l1 w-step: the preconditioned nonlinear CG of k_ncg_init / k_ncg_update in one launch
 template <bool GLDS, int PER>
 __global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __restrict__ G, int ld, const double* __restrict__ q,
-                                                             NcgParams P, int max_iter, double* __restrict__ w, double* x0,
-                                                             double* x1, int xbytes, double* __restrict__ Gw_out, unsigned* bar,
-                                                             int parity, int* pin) {
+                                                             NcgParams P, int max_iter, double* __restrict__ w,
+                                                             unsigned long long* x0, unsigned long long* x1, unsigned tag_base,
+                                                             double* __restrict__ Gw_out, unsigned* abort_word, int* pin) {
     extern __shared__ __attribute__((aligned(16))) double wp_lds[];
     double* xs = wp_lds;
     double* red = wp_lds + ld;
     double* ybuf = red + 16;
-    int* flag = reinterpret_cast<int*>(ybuf + WP_RPB);
     double* gs = ybuf + WP_RPB + 16;
     const int r0 = blockIdx.x * WP_RPB, r1 = min(ld, r0 + WP_RPB);
-    WpBarrier b = wp_barrier_init(bar, parity);
+    unsigned xn = 0;
     wp_stage_rows<GLDS>(G, gs, ld, r0, r1);
     double wj[PER], gwj[PER], pj[PER], sj[PER], gdj[PER], qj[PER], gpj[PER];
 #pragma unroll
@@ -886,7 +872,8 @@ __global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __rest
     wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, ybuf);          // G w
     int iters = 0, done = 0, ok = 1;
     double gs_old = 0.0, thr = 0.0, stalled = 0.0;
-    if (!wp_exchange<PER>(b, ybuf, x0, xbytes, gwj, flag)) ok = 0;
+    ++xn;
+    if (!wp_exchange<PER>(tag_base + xn, ybuf, x0, ld, gwj, abort_word)) ok = 0;
     if (ok) {
         double acc[1] = {0.0};
         double gmax = 0.0, qmax = 0.0;
@@ -920,7 +907,8 @@ __global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __rest
         }
         __syncthreads();
         wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, ybuf);      // G p
-        if (!wp_exchange<PER>(b, ybuf, (iters & 1) ? x0 : x1, xbytes, gpj, flag)) {
+        ++xn;
+        if (!wp_exchange<PER>(tag_base + xn, ybuf, (iters & 1) ? x0 : x1, ld, gpj, abort_word)) {
             ok = 0;
             break;
         }
@@ -1032,7 +1020,7 @@ WpPlan wp_plan(int64_t ld) {
     }();
     p.nblocks = (int)((ld + WP_RPB - 1) / WP_RPB);
     if (p.nblocks > cus) return p;   // at most one block per CU: all blocks resident at once (the device-wide wait needs that)
-    const size_t fixed = sizeof(double) * ((size_t)ld + 16 + WP_RPB + 16);
+    const size_t fixed = sizeof(double) * ((size_t)ld + 16 + WP_RPB + 16);   // p | block sums | this block's rows of the product
     const size_t rows = sizeof(double) * (size_t)WP_RPB * (size_t)ld;
     p.glds = fixed + rows <= 156 * 1024;
     p.lds_bytes = fixed + (p.glds ? rows : 0);
@@ -1053,17 +1041,20 @@ int run_cg_persist(const WpPlan& pl, const double* G, int64_t ld, const double* 
                    int max_iter, double* w, WstepWorkspace& ws, bool want_Gw, int* status, int* iters, hipStream_t s) {
     int* pin = ws.pin + 4;
     pin[0] = -1;
-    const int parity = ws.bar_parity;
-    ws.bar_parity ^= 1;
+    ws.launch_seq = (ws.launch_seq + 1) & 0xfffff;
+    if (ws.launch_seq == 0) ws.launch_seq = 1;
+    const unsigned tag_base = (unsigned)ws.launch_seq << 12;          // exchange tags of this launch: tag_base + 1 ...
+    if (max_iter > 4000) max_iter = 4000;                             // (12 bits of exchange number)
     double* gw = want_Gw ? ws.Gy : nullptr;
-    double *x0 = ws.xch, *x1 = ws.xch + WSTEP_XCH_DOUBLES / 2;
+    unsigned long long *x0 = reinterpret_cast<unsigned long long*>(ws.xch),
+                       *x1 = reinterpret_cast<unsigned long long*>(ws.xch) + WSTEP_XCH_GRANULES;
     // RBL_WPERSIST_DEBUG=1: block 0 leaves 100 MHz wall-clock stamps (start | rows staged | first exchange | loop done |
     // G w written | published) behind the second exchange buffer; printed to stderr after the kernel
     static const bool dbg_on = [] {
         const char* e = getenv("RBL_WPERSIST_DEBUG");
         return e && e[0] == '1';
     }();
-    long long* dbg = dbg_on ? reinterpret_cast<long long*>(ws.xch + WSTEP_XCH_DOUBLES - 8) : nullptr;
+    long long* dbg = dbg_on ? reinterpret_cast<long long*>(ws.xch) + 2 * WSTEP_XCH_GRANULES : nullptr;
 #define RBL_CG_PERSIST(GL, PR)                                                                                           \
     do {                                                                                                                 \
         static size_t lds_set = 0; /* (one attribute call per instantiation and size, not per launch) */                 \
@@ -1072,7 +1063,7 @@ int run_cg_persist(const WpPlan& pl, const double* G, int64_t ld, const double* 
             lds_set = pl.lds_bytes;                                                                                      \
         }                                                                                                                \
         hipLaunchKernelGGL((k_cg_persist<GL, PR>), dim3(pl.nblocks), dim3(WP_THREADS), pl.lds_bytes, s, G, (int)ld, q, rho, \
-                           reg, tol, max_iter, w, x0, x1, pl.xbytes, gw, ws.bar, parity, pin, dbg);                      \
+                           reg, tol, max_iter, w, x0, x1, tag_base, gw, ws.bar, pin, dbg);                               \
     } while (0)
     const bool narrow = ld <= 4 * WP_THREADS;
     if (pl.glds && narrow) RBL_CG_PERSIST(true, 4);
@@ -1098,10 +1089,13 @@ int run_ncg_persist(const WpPlan& pl, const double* G, int64_t ld, const double*
                     WstepWorkspace& ws, bool want_Gw, int* status, int* iters, hipStream_t s) {
     int* pin = ws.pin + 8;
     pin[0] = -1;
-    const int parity = ws.bar_parity;
-    ws.bar_parity ^= 1;
+    ws.launch_seq = (ws.launch_seq + 1) & 0xfffff;
+    if (ws.launch_seq == 0) ws.launch_seq = 1;
+    const unsigned tag_base = (unsigned)ws.launch_seq << 12;
+    if (max_iter > 4000) max_iter = 4000;
     double* gw = want_Gw ? ws.Gy : nullptr;
-    double *x0 = ws.xch, *x1 = ws.xch + WSTEP_XCH_DOUBLES / 2;
+    unsigned long long *x0 = reinterpret_cast<unsigned long long*>(ws.xch),
+                       *x1 = reinterpret_cast<unsigned long long*>(ws.xch) + WSTEP_XCH_GRANULES;
 #define RBL_NCG_PERSIST(GL, PR)                                                                                          \
     do {                                                                                                                 \
         static size_t lds_set = 0;                                                                                       \
@@ -1110,7 +1104,7 @@ int run_ncg_persist(const WpPlan& pl, const double* G, int64_t ld, const double*
             lds_set = pl.lds_bytes;                                                                                      \
         }                                                                                                                \
         hipLaunchKernelGGL((k_ncg_persist<GL, PR>), dim3(pl.nblocks), dim3(WP_THREADS), pl.lds_bytes, s, G, (int)ld, q, P, \
-                           max_iter, w, x0, x1, pl.xbytes, gw, ws.bar, parity, pin);                                     \
+                           max_iter, w, x0, x1, tag_base, gw, ws.bar, pin);                                              \
     } while (0)
     const bool narrow = ld <= 4 * WP_THREADS;
     if (pl.glds && narrow) RBL_NCG_PERSIST(true, 4);
