@@ -196,5 +196,8 @@ def test_uncertified_z_step_redo_is_bit_identical_with_the_lasso(R, monkeypatch)
     first_certified = modes.index(1) if 1 in modes else nit
     assert 2 in modes[:first_certified], modes          # at least one redone iteration was compared
     for k in range(first_certified):
-        assert a[k][1:4] == b[k][1:4], (k, modes)
+        assert a[k][1:3] == b[k][1:3], (k, modes)                # primal and dual residual: the same bits
         assert np.array_equal(a[k][4], b[k][4]) and np.array_equal(a[k][5], b[k][5]), (k, modes)
+        # the LOGGED objective of banded weights is summed per band by the sort-free risk kernel when the fast path is
+        # on and along the sorted losses when it is off: the same number in a different order of additions
+        assert abs(a[k][3] - b[k][3]) <= 1e-12 * max(1.0, abs(a[k][3])), (k, modes)

@@ -58,6 +58,14 @@ int main(int argc, char** argv) {
     RUN1("full, 1 block/CU", 4, 2, 8, false, 0, cu);
     RUN1("full, R=4 S=4 w in LDS", 4, 4, 4, true, 0, 2 * cu);
     RUN1("v-only (rank-weighted problems)", 4, 2, 8, false, SE_VONLY, 2 * cu);
+    RUN1("v-only, no row writes", 4, 2, 8, false, SE_VONLY | 1, 2 * cu);
+    RUN1("v-only, no wave reduce", 4, 2, 8, false, SE_VONLY | 8, 2 * cu);
+    RUN1("v-only, no side loads", 4, 2, 8, false, SE_VONLY | 32, 2 * cu);
+    RUN1("v-only, no writes/reduce/side", 4, 2, 8, false, SE_VONLY | 1 | 8 | 32, 2 * cu);
+    RUN1("q-only (D^T c)", 4, 2, 8, false, SE_QONLY, 2 * cu);
+    RUN1("q-only R=4 S=4", 4, 4, 4, false, SE_QONLY, 2 * cu);
+    RUN1("q-only, 1 block/CU", 4, 2, 8, false, SE_QONLY, cu);
+    RUN1("q-only, 3 blocks/CU", 4, 2, 8, false, SE_QONLY, 3 * cu);
     RUN1("no row writes", 4, 2, 8, false, 1, 2 * cu);
     RUN1("no acc phase", 4, 2, 8, false, 2, 2 * cu);
     RUN1("no prox", 4, 2, 8, false, 4, 2 * cu);
