@@ -42,6 +42,31 @@ template <> struct Pk<double> {
 
 constexpr int SE_THREADS = 256;
 
+// Row-wise stores of the single-sweep kernels (lambda, v, z': 8 bytes per row and array, whole 128-byte lines per
+// super-batch) are WRITE-THROUGH (sc1).  They are 0.4 % of the pass's bytes but cost 8 % of its time as plain stores
+// (tools/sweep_lab.hip, 6M x 1000 fp32: v-only pass 3.81 ms, 3.39 without them, 3.40 when they go to a ring that stays
+// in L2 - so it is not their issue but their way to HBM: dirty lines evicted from the write-back L2 by the streaming
+// reads); written through they leave in order: 3.59 ms (nt 3.70; sc0 / sc1 nt / buffer-store forms the same as sc1).
+// The EXP bits 256 / 512 / 2048 / 4096 exist for tools/sweep_lab.hip only (256: into a 1024-row ring, 512: non-temporal,
+// 2048 + aux in bits 13-17: raw buffer store with that cache-policy field, 4096: plain stores as in round 2).
+template <int EXP>
+__device__ inline void row_store(double* __restrict__ base, long long row, double x) {
+    if (EXP & 256) row &= 1023;
+    if (EXP & 2048) {
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+        v2u val;
+        val.x = (unsigned)b;
+        val.y = (unsigned)(b >> 32);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b64(val, rs, (int)(row * 8), 0, (EXP >> 13) & 31);
+    } else if (EXP & 512) __builtin_nontemporal_store(x, base + row);
+    else if (EXP & 4096) base[row] = x;
+    else
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(base + row), __builtin_bit_cast(unsigned long long, x), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // fp32 storage: hide the packets from the optimiser between the dot phase and the accumulation
 // phase (otherwise the widened fp64 copies of the dot phase are kept alive: 2 VGPRs per element)
 template <typename T, int R, int P>
@@ -236,9 +261,9 @@ __global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
             process(live, sub, bufA, zo, lm);
             if (last && lane < live && !(EXP & 1)) {
                 const long long row = (long long)q * SR + lane;
-                lam[row] = l_out;
-                if (v) v[row] = v_out;   // NULL: nobody reads v before the next pass (no objective logging)
-                if (!(EXP & 128)) z_new[row] = z_out;
+                row_store<EXP>(lam, row, l_out);
+                if (v) row_store<EXP>(v, row, v_out);   // NULL: nobody reads v before the next pass (no objective logging)
+                if (!(EXP & 128)) row_store<EXP>(z_new, row, z_out);
             }
             q = qn;
             sub = subn;
@@ -468,9 +493,9 @@ __global__ __launch_bounds__(SEW_THREADS, 1) void k_sweep_erm_wide(
         if (last) {
             if (tid < live) {
                 const long long row = (long long)q * SR + tid;
-                lam[row] = l_out;
-                if (v) v[row] = v_out;   // NULL: nobody reads v before the next pass (no objective logging)
-                z_new[row] = z_out;
+                row_store<0>(lam, row, l_out);
+                if (v) row_store<0>(v, row, v_out);   // NULL: nobody reads v before the next pass (no objective logging)
+                row_store<0>(z_new, row, z_out);
             }
         }
         q = qn;

@@ -59,6 +59,22 @@ int main(int argc, char** argv) {
     RUN1("full, R=4 S=4 w in LDS", 4, 4, 4, true, 0, 2 * cu);
     RUN1("v-only (rank-weighted problems)", 4, 2, 8, false, SE_VONLY, 2 * cu);
     RUN1("v-only, no row writes", 4, 2, 8, false, SE_VONLY | 1, 2 * cu);
+    RUN1("v-only, writes into an L2 ring", 4, 2, 8, false, SE_VONLY | 256, 2 * cu);
+    RUN1("v-only, nt stores", 4, 2, 8, false, SE_VONLY | 512, 2 * cu);
+    RUN1("v-only, plain stores (round 2)", 4, 2, 8, false, SE_VONLY | 4096, 2 * cu);
+    RUN1("v-only, buffer store aux=0", 4, 2, 8, false, SE_VONLY | 2048 | (0 << 13), 2 * cu);
+    RUN1("v-only, buffer store sc0", 4, 2, 8, false, SE_VONLY | 2048 | (1 << 13), 2 * cu);
+    RUN1("v-only, buffer store nt", 4, 2, 8, false, SE_VONLY | 2048 | (2 << 13), 2 * cu);
+    RUN1("v-only, buffer store sc1", 4, 2, 8, false, SE_VONLY | 2048 | (16 << 13), 2 * cu);
+    RUN1("v-only, buffer store sc0 sc1", 4, 2, 8, false, SE_VONLY | 2048 | (17 << 13), 2 * cu);
+    RUN1("v-only, buffer store sc1 nt", 4, 2, 8, false, SE_VONLY | 2048 | (18 << 13), 2 * cu);
+    RUN1("v-only, buffer store sc0 sc1 nt", 4, 2, 8, false, SE_VONLY | 2048 | (19 << 13), 2 * cu);
+    RUN1("v-only, S*R = 64 rows", 4, 4, 16, false, SE_VONLY, 2 * cu);
+    RUN1("v-only, 1 block/CU", 4, 2, 8, false, SE_VONLY, cu);
+    RUN1("v-only, R=1 S=16", 4, 1, 16, false, SE_VONLY, 2 * cu);
+    RUN1("full, writes into an L2 ring", 4, 2, 8, false, 256, 2 * cu);
+    RUN1("full, nt stores", 4, 2, 8, false, 512, 2 * cu);
+    RUN1("full, plain stores (round 2)", 4, 2, 8, false, 4096, 2 * cu);
     RUN1("v-only, no wave reduce", 4, 2, 8, false, SE_VONLY | 8, 2 * cu);
     RUN1("v-only, no side loads", 4, 2, 8, false, SE_VONLY | 32, 2 * cu);
     RUN1("v-only, no writes/reduce/side", 4, 2, 8, false, SE_VONLY | 1 | 8 | 32, 2 * cu);
@@ -66,6 +82,13 @@ int main(int argc, char** argv) {
     RUN1("q-only R=4 S=4", 4, 4, 4, false, SE_QONLY, 2 * cu);
     RUN1("q-only, 1 block/CU", 4, 2, 8, false, SE_QONLY, cu);
     RUN1("q-only, 3 blocks/CU", 4, 2, 8, false, SE_QONLY, 3 * cu);
+    {
+        double* vsave = v;
+        v = nullptr;
+        RUN1("v-only, lambda store only (v NULL)", 4, 2, 8, false, SE_VONLY, 2 * cu);
+        RUN1("full, lambda + z' stores only (v NULL)", 4, 2, 8, false, 0, 2 * cu);
+        v = vsave;
+    }
     RUN1("no row writes", 4, 2, 8, false, 1, 2 * cu);
     RUN1("no acc phase", 4, 2, 8, false, 2, 2 * cu);
     RUN1("no prox", 4, 2, 8, false, 4, 2 * cu);
