@@ -691,6 +691,17 @@ int sweep_erm_blocks(int num_cu) {   // 2 blocks of 4 waves per CU (2 waves per 
     return num_cu * per_cu;
 }
 int sweep_erm_slab_rows(int num_cu) { return sweep_erm_blocks(num_cu) + CR_SLICES; }
+// the v-only and q-only passes (one half of the fused pass each) run best with ONE block of 4 waves per CU: interleaved
+// on one box C2sq 134.6 -> 137.4 it/s (the fused pass the other way round: 270 it/s with two blocks, 236 with one);
+// RBL_SWEEPVQ_BLOCKS_PER_CU=2 for experiments
+static int sweep_vq_blocks(int num_cu) {
+    static const int per_cu = [] {
+        const char* e = getenv("RBL_SWEEPVQ_BLOCKS_PER_CU");
+        const int v = e ? atoi(e) : 1;
+        return (v == 1 || v == 2) ? v : 1;
+    }();
+    return num_cu * per_cu;
+}
 
 int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld, const double* w, const double* z_old,
                      double* lam, double* v, double* z_new, double sigma0, double rho, const double* pred_dev,
@@ -769,7 +780,7 @@ bool sweep_v_supported(int storage, int64_t ld) {
 
 int launch_sweep_v(int storage, const void* D, int64_t n, int64_t ld, const double* w, const double* z, double* lam,
                    double* v, double rho, double* partials, double* red, int num_cu, hipStream_t s, hipEvent_t main_done) {
-    const int grid = sweep_erm_blocks(num_cu);
+    const int grid = sweep_vq_blocks(num_cu);
     if (storage == RBL_STORE_F32)
         RBL_TRY(launch_v_T<float>((const float*)D, n, ld, w, z, lam, v, rho, partials, grid, s));
     else
@@ -824,7 +835,7 @@ bool sweep_q_supported(int storage, int64_t ld) {
 
 int launch_sweep_q(int storage, const void* D, int64_t n, int64_t ld, const double* c, double* slab, double* q, int num_cu,
                    hipStream_t s, hipEvent_t main_done) {
-    const int grid = sweep_erm_blocks(num_cu);
+    const int grid = sweep_vq_blocks(num_cu);
     if (storage == RBL_STORE_F32)
         RBL_TRY(launch_q_T<float>((const float*)D, n, ld, c, slab, grid, s));
     else
