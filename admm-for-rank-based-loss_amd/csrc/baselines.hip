@@ -37,7 +37,7 @@ struct rbl_baseline {
 namespace {
 
 constexpr int BL_THREADS = 256;
-constexpr int BL_MAX_BATCH = 256;
+constexpr int BL_MAX_BATCH = 1024;   // one thread of the SGD workgroup per mini-batch row (the reference's drivers use 64; SGD_solver.py:9 takes any size)
 
 template <int LOSS>
 __device__ inline double bl_loss(double z, double y) {

@@ -46,13 +46,15 @@ def test_baselines_vs_reference_goldens(R, k):
                            args=[0.5], batch_size=50)),
     ("sgd", 3001, 130, dict(weight_function="ehrm", loss="binary_cross_entropy", l2_reg=1.0, lr=0.02, max_iter=3, lossB=0.69)),
     ("sgd", 2000, 9, dict(weight_function="aorr", loss="hinge", l1_reg=1.0, lr=0.05, max_iter=3, args=[0.2, 0.8], batch_size=256)),
+    ("sgd", 6000, 21, dict(weight_function="superquantile", loss="binary_cross_entropy", l2_reg=1.0, lr=0.05, max_iter=3,
+                           args=[0.5], batch_size=1000)),      # (mini-batches up to 1024 rows: one thread of the workgroup per row)
     ("lsvrg", 20000, 64, dict(weight_function="extremile", loss="binary_cross_entropy", l2_reg=1.0, lr=0.01, max_iter=3,
                               args=[2.0], uniform=None)),
     ("lsvrg", 7001, 21, dict(weight_function="ehrm", loss="binary_cross_entropy", l1_reg=1.0, lr=0.01, max_iter=3, lossB=0.69,
                              uniform=True)),
     ("lsvrg", 4000, 1001, dict(weight_function="aorr_dc", loss="hinge", l2_reg=1.0, lr=0.005, max_iter=2, args=[900, 40],
                                uniform=None)),
-], ids=["sgd_superq_b50", "sgd_ehrm_d130", "sgd_aorr_hinge_l1_b256", "lsvrg_extremile_20000", "lsvrg_ehrm_l1_uniform",
+], ids=["sgd_superq_b50", "sgd_ehrm_d130", "sgd_aorr_hinge_l1_b256", "sgd_superq_b1000", "lsvrg_extremile_20000", "lsvrg_ehrm_l1_uniform",
         "lsvrg_aorr_dc_hinge_d1001"])
 def test_baselines_vs_oracle(R, algo, n, d, kw):
     import torch
