@@ -13,7 +13,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$ROOT/profiles"
 export TMPDIR=/tmp
 cd "$ROOT"
-B="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-gap --no-c1"
+B="bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gap --no-c1"   # the driver's command (its extra records left out)
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c2" -o c2 -- python3 $B > "$OUT/c2.log" 2>&1
 cp "$(find "$OUT/c2" -name 'c2_kernel_stats.csv' | head -1)" "profiles/${TAG}_C2_fused_kernel_stats.csv"

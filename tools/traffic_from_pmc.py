@@ -46,8 +46,14 @@ def main():
             short = "gemvt"
         elif "k_gemv<" in k:
             short = "gemv"
-        elif "k_sweep_erm" in k:
+        elif "k_sweep_erm_wide<" in k:
             short = "sweep_erm"
+        elif "k_sweep_erm<" in k:
+            # k_sweep_erm<T, LOSS, P, R, S, WL, EXP, ONE>: EXP = 0 is the fused pass; 134 the v-only pass (timed in the
+            # library's gemv slot), 93 the q-only pass (its gemvt slot)
+            targs = k.split("k_sweep_erm<", 1)[1].split(">", 1)[0].split(",")
+            exp = int(targs[6]) if len(targs) > 6 and targs[6].strip().lstrip("-").isdigit() else 0
+            short = {0: "sweep_erm", 134: "sweep_v", 93: "sweep_q"}.get(exp)
         if short:
             kernels[short] = dict(kernel=k, launches=nf, fetch_size_kib=f, write_size_kib=w,
                                   hbm_bytes_per_launch=hbm)
