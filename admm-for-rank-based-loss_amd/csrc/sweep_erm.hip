@@ -633,7 +633,15 @@ int launch_T(const T* D, long long n, long long ld, const double* w, const doubl
     const long long passes = (PK + 63) / 64;
     if (passes == 1) return launch_one<T, LOSS, 1, 8, 2, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
     if (passes == 2) return launch_one<T, LOSS, 2, 4, 4, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
-    if (passes <= 4) return launch_one<T, LOSS, 4, 2, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+    if (passes <= 4) {
+        static const int shape = [] {
+            const char* e = getenv("RBL_SWEEP_SHAPE");   // experiments: 1 = four rows per sub-batch with w in LDS, 2 = four rows, w in registers
+            return e ? atoi(e) : 0;
+        }();
+        if (shape == 1) return launch_one<T, LOSS, 4, 4, 4, true>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+        if (shape == 2 && sizeof(T) == 4) return launch_one<T, LOSS, 4, 4, 4, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+        return launch_one<T, LOSS, 4, 2, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+    }
     if (passes <= 8 && sizeof(T) == 8) {
         if constexpr (sizeof(T) == 8)
             return launch_one<T, LOSS, 8, 1, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);

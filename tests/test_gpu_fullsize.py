@@ -284,6 +284,7 @@ def test_full_size_properties(R, name, monkeypatch):
         assert abs(st.objective - f_ref) <= 1e-10 * max(1.0, abs(f_ref)), (st.objective, f_ref)
         if it == nit - 1:
             w_last, v_last = w, v
+    print("full-size %s: rbl_stats.zband per iteration %s" % (name, modes))      # (pytest -s shows it)
     # ---- which z-step the KKT check above has seen (rbl_stats.zband: 0 sort + PAV, 1 sort-free and certified,
     # 2 sort-free, not certified, redone with the sort; -1 erm)
     if name in ("C2sq", "C3"):
