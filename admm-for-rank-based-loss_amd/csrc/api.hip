@@ -4,6 +4,7 @@
 // every arithmetic step runs in a HIP kernel; there is no CPU fallback.
 #include "rbl_internal.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -28,8 +29,14 @@ void rbl_set_error(const char* fmt, ...) {
 }
 
 // -------------------------------------------------------------------------------- handle
+// live handles per device: a persistent w-step kernel needs all its blocks resident at once (one per CU: its G rows
+// fill the LDS), which only holds while no second such kernel of this process can occupy CUs beside it
+static std::atomic<int> g_live[64];
+int rbl_live_handles(int device) { return device >= 0 && device < 64 ? g_live[device].load(std::memory_order_relaxed) : 2; }
+
 struct rbl_solver {
     rbl_config cfg;
+    bool counted = false;
     int64_t n = 0, d = 0, ld = 0, nt = 0, off = 0;
     int storage = 0;
     size_t esz = 4;
@@ -593,6 +600,7 @@ int rbl_destroy(rbl_solver* h) {
     for (auto& e : h->kev) if (e) (void)hipEventDestroy(e);
     for (auto& e : h->ev_spec) if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->counted) g_live[h->cfg.device].fetch_sub(1, std::memory_order_relaxed);
     delete h;
     return RBL_OK;
 }
@@ -613,6 +621,10 @@ int rbl_create(const rbl_config* cfg, rbl_solver** out) {
     RBL_HIP(hipSetDevice(cfg->device));
     rbl_solver* h = new rbl_solver();
     h->cfg = *cfg;
+    if (cfg->device < 64) {
+        g_live[cfg->device].fetch_add(1, std::memory_order_relaxed);
+        h->counted = true;
+    }
     h->n = cfg->n;
     h->d = cfg->d;
     h->ld = round_up(cfg->d, 4);

@@ -134,6 +134,7 @@ struct PavExtras {
     double B;
 };
 size_t pav_bar_uints();
+int rbl_live_handles(int device);   // api.hip: solver handles of this process alive on a device
 int64_t pav_big_recs();
 int64_t pav_fpart_doubles(int64_t n);
 struct PavWorkspace {

@@ -91,8 +91,8 @@ constexpr int SE_VONLY = 2 | 4 | 128;   // no accumulation phase, no prox, no z'
 // block.  The thread-per-column-packet k_gemvt reads the same bytes at 6.0 TB/s, this kernel at the single-sweep
 // kernel's 6.2-6.5 (buffer loads through scalar row descriptors, a whole sub-batch of rows in flight per wave).
 constexpr int SE_QONLY = 1 | 4 | 8 | 16 | 64;
-template <typename T, int LOSS, int P, int R, int S, bool WL, int EXP = 0, bool ONE = false>
-__global__ __launch_bounds__(SE_THREADS, 2) void k_sweep_erm(
+template <typename T, int LOSS, int P, int R, int S, bool WL, int EXP = 0, bool ONE = false, int OCC = 2>
+__global__ __launch_bounds__(SE_THREADS, OCC) void k_sweep_erm(
     const T* __restrict__ D, long long n, long long ld, const double* __restrict__ w, const double* __restrict__ z_old,
     double* __restrict__ lam, double* __restrict__ v, double* __restrict__ z_new, double sigma0, double rho,
     const double* __restrict__ pred, double* __restrict__ slab, double* __restrict__ partials) {
@@ -615,11 +615,11 @@ __global__ __launch_bounds__(256) void k_sumsq(long long n, const double* __rest
     if (threadIdx.x == 0) partials[blockIdx.x] = a[0];
 }
 
-template <typename T, int LOSS, int P, int R, int S, bool WL>
+template <typename T, int LOSS, int P, int R, int S, bool WL, int OCC = 2>
 int launch_one(const T* D, long long n, long long ld, const double* w, const double* z_old, double* lam, double* v,
                double* z_new, double sigma0, double rho, const double* pred, double* slab, double* partials, int grid,
                hipStream_t s) {
-    hipLaunchKernelGGL((k_sweep_erm<T, LOSS, P, R, S, WL, 0, true>), dim3(grid), dim3(SE_THREADS), 0, s, D, n, ld, w, z_old, lam, v,
+    hipLaunchKernelGGL((k_sweep_erm<T, LOSS, P, R, S, WL, 0, true, OCC>), dim3(grid), dim3(SE_THREADS), 0, s, D, n, ld, w, z_old, lam, v,
                        z_new, sigma0, rho, pred, slab, partials);
     RBL_HIP(hipGetLastError());
     return RBL_OK;
@@ -628,27 +628,55 @@ int launch_one(const T* D, long long n, long long ld, const double* w, const dou
 template <typename T, int LOSS>
 int launch_T(const T* D, long long n, long long ld, const double* w, const double* z_old, double* lam, double* v,
              double* z_new, double sigma0, double rho, const double* pred, double* slab, double* partials, int grid,
-             hipStream_t s) {
+             int num_cu, int* used, hipStream_t s) {
     const long long PK = ld / Pk<T>::E;
     const long long passes = (PK + 63) / 64;
+    *used = grid;
     if (passes == 1) return launch_one<T, LOSS, 1, 8, 2, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
     if (passes == 2) return launch_one<T, LOSS, 2, 4, 4, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+    // 3-4 (fp64 storage: 5-8) packets per lane: ONE block of 4 waves per CU, four (two) rows per sub-batch and two
+    // sub-batch buffers - 32 KB of loads in flight per wave - with w in LDS.  Round 2's shape (two rows per sub-batch,
+    // two blocks per CU, w in registers) is 5 % slower at 6M x 1000 and ramps over its first ~25 launches after an idle
+    // gap (3.93 -> 3.66 ms; this shape 3.57 -> 3.48): interleaved on one box, C2 266-271 it/s against 281-283
+    // (profiles/r03_sweep_shapes.txt).  Fewer waves, each with more rows in flight, stream better than more waves:
+    // with 8 waves per CU the same rows-in-flight give 276-278.  RBL_SWEEP_SHAPE=0 is round 2's shape, 1 the
+    // two-blocks-per-CU form of the default, 8 eight rows per sub-batch (same speed as the default).
+    static const int shape = [] {
+        const char* e = getenv("RBL_SWEEP_SHAPE");
+        return e ? atoi(e) : -1;
+    }();
+    static const int bpc1 = [] {
+        const char* e = getenv("RBL_SWEEP_BLOCKS_PER_CU");
+        const int v = e ? atoi(e) : 1;
+        return (v >= 1 && v <= 2) ? v : 1;
+    }();
+#define RBL_ONE(P_, R_, S_, WL_)                                                                                              \
+    do {                                                                                                                      \
+        *used = num_cu * bpc1;                                                                                                \
+        return launch_one<T, LOSS, P_, R_, S_, WL_, 1>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, \
+                                                       num_cu * bpc1, s);                                                     \
+    } while (0)
     if (passes <= 4) {
-        static const int shape = [] {
-            const char* e = getenv("RBL_SWEEP_SHAPE");   // experiments: 1 = four rows per sub-batch with w in LDS, 2 = four rows, w in registers
-            return e ? atoi(e) : 0;
-        }();
+        if (shape == 0) return launch_one<T, LOSS, 4, 2, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
         if (shape == 1) return launch_one<T, LOSS, 4, 4, 4, true>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
-        if (shape == 2 && sizeof(T) == 4) return launch_one<T, LOSS, 4, 4, 4, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
-        return launch_one<T, LOSS, 4, 2, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+        if (shape == 8) RBL_ONE(4, 8, 2, true);
+        RBL_ONE(4, 4, 4, true);
     }
     if (passes <= 8 && sizeof(T) == 8) {
-        if constexpr (sizeof(T) == 8)
+        if constexpr (sizeof(T) == 8) {
+            if (shape == 0) return launch_one<T, LOSS, 8, 1, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+            if (shape == 1) return launch_one<T, LOSS, 8, 2, 4, true>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+            if (shape == 8) RBL_ONE(8, 4, 4, true);
+            if (shape == 9) RBL_ONE(8, 2, 8, true);
+            if (shape == 10) RBL_ONE(8, 2, 4, true);
             return launch_one<T, LOSS, 8, 1, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+        }
     }
+#undef RBL_ONE
     // wider rows: one workgroup of 512 threads per row batch (grid = one workgroup per CU)
     const long long pt = (PK + SEW_THREADS - 1) / SEW_THREADS;
     const int wgrid = grid / 2;
+    *used = wgrid;
 #define RBL_WIDE(PT_, R_, S_)                                                                                          \
     do {                                                                                                               \
         auto kfn = k_sweep_erm_wide<T, LOSS, PT_, R_, S_>;                                                             \
@@ -690,17 +718,13 @@ static bool sweep_erm_is_wide(int storage, int64_t ld) {
     return PK > (storage == RBL_STORE_F32 ? 256 : 512);
 }
 
-int sweep_erm_blocks(int num_cu) {   // 2 blocks of 4 waves per CU (2 waves per SIMD); RBL_SWEEP_BLOCKS_PER_CU=1 for experiments
-    static const int per_cu = [] {
-        const char* e = getenv("RBL_SWEEP_BLOCKS_PER_CU");
-        const int v = e ? atoi(e) : 2;
-        return (v == 1 || v == 2) ? v : 2;
-    }();
-    return num_cu * per_cu;
-}
+// upper bound of the blocks a single-sweep launch uses (slab rows, partial triples): 2 per CU; the shapes that run one
+// block per CU (launch_T) use the first half
+int sweep_erm_blocks(int num_cu) { return num_cu * 2; }
 int sweep_erm_slab_rows(int num_cu) { return sweep_erm_blocks(num_cu) + CR_SLICES; }
 // the v-only and q-only passes (one half of the fused pass each) run best with ONE block of 4 waves per CU: interleaved
-// on one box C2sq 134.6 -> 137.4 it/s (the fused pass the other way round: 270 it/s with two blocks, 236 with one);
+// on one box C2sq 134.6 -> 137.4 it/s (the fused pass with two rows per sub-batch the other way round, 270 it/s with two
+// blocks and 236 with one; with four rows per sub-batch it too runs best with one block, launch_T);
 // RBL_SWEEPVQ_BLOCKS_PER_CU=2 for experiments
 static int sweep_vq_blocks(int num_cu) {
     static const int per_cu = [] {
@@ -716,18 +740,18 @@ int launch_sweep_erm(int storage, int loss, const void* D, int64_t n, int64_t ld
                      double* slab, double* partials, double* q, double* red, double* zz_out, int num_cu, hipStream_t s,
                      hipEvent_t main_done, int want_obj) {
     const int grid = sweep_erm_blocks(num_cu);
-    const int nrows = sweep_erm_is_wide(storage, ld) ? grid / 2 : grid;   // slab rows / partial triples produced
+    int nrows = grid;   // slab rows / partial triples produced = blocks launched
     double* const v_for_loss = v;
     if (!want_obj) v = nullptr;   // 8 of the 24 B/row of row-wise stores: only the loss sum reads v after the pass
     int rc;
     if (storage == RBL_STORE_F32) {
         rc = (loss == RBL_LOSS_BCE)
-                 ? launch_T<float, 0>((const float*)D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred_dev, slab, partials, grid, s)
-                 : launch_T<float, 1>((const float*)D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred_dev, slab, partials, grid, s);
+                 ? launch_T<float, 0>((const float*)D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred_dev, slab, partials, grid, num_cu, &nrows, s)
+                 : launch_T<float, 1>((const float*)D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred_dev, slab, partials, grid, num_cu, &nrows, s);
     } else {
         rc = (loss == RBL_LOSS_BCE)
-                 ? launch_T<double, 0>((const double*)D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred_dev, slab, partials, grid, s)
-                 : launch_T<double, 1>((const double*)D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred_dev, slab, partials, grid, s);
+                 ? launch_T<double, 0>((const double*)D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred_dev, slab, partials, grid, num_cu, &nrows, s)
+                 : launch_T<double, 1>((const double*)D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred_dev, slab, partials, grid, num_cu, &nrows, s);
     }
     RBL_TRY(rc);
     if (main_done) RBL_HIP(hipEventRecord(main_done, s));
@@ -770,7 +794,7 @@ int launch_v_T(const T* D, long long n, long long ld, const double* w, const dou
     } while (0)
     if (passes == 1) RBL_V(1, 8, 2);
     if (passes == 2) RBL_V(2, 4, 4);
-    if (passes <= 4) RBL_V(4, 2, 8);
+    if (passes <= 4) RBL_V(4, 2, 8);   // (four rows per sub-batch: no gain here, 3.50 against 3.46-3.50 ms at 6M x 1000)
     if constexpr (sizeof(T) == 8) {
         if (passes <= 8) RBL_V(8, 1, 8);
     }

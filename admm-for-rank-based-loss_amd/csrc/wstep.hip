@@ -1013,6 +1013,17 @@ WpPlan wp_plan(int64_t ld) {
         return (e && e[0] == '0') ? 0 : 1;
     }();
     if (!enabled || ld > WSTEP_PERSIST_MAX_LD || ld < 4) return p;
+    {
+        // several handles of this process on one device (threads as ranks, the test rigs): two persistent kernels side by
+        // side can each hold some CUs and wait for blocks the other keeps out - the batched launches serve there.
+        // RBL_WSTEP_PERSIST=2 keeps the persistent form regardless (lab).
+        static const int force = [] {
+            const char* e = getenv("RBL_WSTEP_PERSIST");
+            return (e && e[0] == '2') ? 1 : 0;
+        }();
+        int dev = 0;
+        if (!force && (hipGetDevice(&dev) != hipSuccess || rbl_live_handles(dev) > 1)) return p;
+    }
     static const int cus = [] {
         int dev = 0, c = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);

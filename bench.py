@@ -331,32 +331,37 @@ def main():
     s = rbl.Solver(n_local, d, cfg["weight_function"], cfg["loss"], reg=cfg["reg"], wstep=cfg["wstep"], B=cfg["B"],
                    args=cfg["args"], storage=a.storage, device=local_rank, n_total=n_total, row_offset=off,
                    tol=0.0)   # tol 0: a fixed number of iterations, never "converged"
+    # Everything that makes the device wait for the host happens BEFORE the last piece of set-up work on the device
+    # (the Gram product): the sweep runs ~5 % slower for its first ~25 launches after the device has sat idle for
+    # 5 ms or more (shader-clock DPM, DESIGN section 5 "the ramp"; tools/ramp_probe.py) but not after compute
+    # kernels.  Round 2 had a gc.collect() and the profiling set-up (~40 ms of idle device) between the warm-up and
+    # the timed region, the first half of round 3 had them between the set-up and the warm-up; now the device goes
+    # Gram product -> warm-up -> timed steps without a host-side pause.
+    import gc
+
+    def quiet_host():
+        s.profile_kernels(2 if a.phase_times else 1)
+        # HIP events around every launch of the sweep kernels at N = 1 (two event records cost ~11 us of stream
+        # time, 0.3 % of a 4 ms pass); every 4th one with several GPUs, where a rank's pass is 0.55 ms
+        s.profile_sampling(1 if world == 1 else (4 if a.steps >= 16 else 1))
+        gc.collect()
+        gc.disable()      # no collector pause inside the timed region (with N ranks the slowest one sets the pace)
+
     if sharded:
         drv = ShardedADMM(GpuEngine(s, local_rank))
         drv.always_allreduce = a.sharded_driver
         drv.setup_synthetic(a.seed)
+        quiet_host()
         drv.setup_gram()
         step = lambda: drv.step(False)
     else:
         s.generate_synthetic(a.seed)
+        quiet_host()
         s.gram()
         step = lambda: s.step(False)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
-
-    # Everything that makes the device wait for the host happens BEFORE the warm-up: the sweep runs ~20 % slower
-    # for its first ~20 launches after the device has sat idle for a few tens of milliseconds (clock / power
-    # state, DESIGN section 5 "the ramp"; tools/ramp_probe.py), and round 2's bench put a gc.collect() and the
-    # profiling set-up (a stream synchronisation) - about 40 ms of idle device - between the warm-up and the
-    # timed region, so every run re-entered that ramp at its first timed step.
-    s.profile_kernels(2 if a.phase_times else 1)
-    # HIP events around every launch of the sweep kernels at N = 1 (two event records cost ~11 us of stream time,
-    # 0.3 % of a 4 ms pass); every 4th one with several GPUs, where a rank's pass is 0.55 ms
     prof_every = 1 if world == 1 else (4 if a.steps >= 16 else 1)
-    s.profile_sampling(prof_every)
-    import gc
-    gc.collect()
-    gc.disable()      # no collector pause inside the timed region (with N ranks the slowest one sets the pace)
     for _ in range(a.warmup):
         step()
     s.reset_kernel_times()      # host bookkeeping only: the device goes straight from the warm-up into the timed steps
