@@ -344,13 +344,13 @@ __global__ __launch_bounds__(SE_THREADS, OCC) void k_sweep_erm(
 // row buffers and the column sums.
 constexpr int SEW_THREADS = 512;
 
-template <typename T, int LOSS, int PT, int R, int S>
-__global__ __launch_bounds__(SEW_THREADS, 1) void k_sweep_erm_wide(
+template <typename T, int LOSS, int PT, int R, int S, int NT = SEW_THREADS>
+__global__ __launch_bounds__(NT, 1) void k_sweep_erm_wide(
     const T* __restrict__ D, long long n, long long ld, const double* __restrict__ w, const double* __restrict__ z_old,
     double* __restrict__ lam, double* __restrict__ v, double* __restrict__ z_new, double sigma0, double rho,
     const double* __restrict__ pred, double* __restrict__ slab, double* __restrict__ partials) {
     constexpr int E = Pk<T>::E;
-    constexpr int NW = SEW_THREADS / 64;
+    constexpr int NW = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int PK = (int)(ld / E);
     const unsigned row_bytes = (unsigned)ld * (unsigned)sizeof(T);
@@ -361,11 +361,11 @@ __global__ __launch_bounds__(SEW_THREADS, 1) void k_sweep_erm_wide(
     int boff[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
-        int pkp = tid + SEW_THREADS * p;
+        int pkp = tid + NT * p;
         const bool ok = pkp < PK;
 #pragma unroll
         for (int k = 0; k < E; ++k) {
-            sw_wide[(p * SEW_THREADS + tid) * E + k] = ok ? w[(long long)pkp * E + k] : 0.0;
+            sw_wide[(p * NT + tid) * E + k] = ok ? w[(long long)pkp * E + k] : 0.0;
             acc[p][k] = 0.0;
         }
         // packets past the row end: an offset outside the row descriptor - the range check returns 0
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(SEW_THREADS, 1) void k_sweep_erm_wide(
         for (int p = 0; p < PT; ++p) {
             double wv[E];
 #pragma unroll
-            for (int k = 0; k < E; ++k) wv[k] = sw_wide[p * SEW_THREADS * E + woff + k];
+            for (int k = 0; k < E; ++k) wv[k] = sw_wide[p * NT * E + woff + k];
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(SEW_THREADS, 1) void k_sweep_erm_wide(
     // every thread owns its columns: the slab row of this workgroup is written directly
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
-        const int pkp = tid + SEW_THREADS * p;
+        const int pkp = tid + NT * p;
         if (pkp < PK) {
 #pragma unroll
             for (int k = 0; k < E; ++k) slab[(long long)blockIdx.x * ld + (long long)pkp * E + k] = acc[p][k];
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(SEW_THREADS, 1) void k_sweep_erm_wide(
     __syncthreads();
     double sums[3] = {s_prim, 0.0, s_zz};
     __shared__ double smem[3 * NW];
-    rbl::block_sum<3, SEW_THREADS>(sums, smem);
+    rbl::block_sum<3, NT>(sums, smem);
     if (tid == 0) {
         partials[blockIdx.x * 3 + 0] = sums[0];
         partials[blockIdx.x * 3 + 1] = sums[1];
@@ -664,12 +664,10 @@ int launch_T(const T* D, long long n, long long ld, const double* w, const doubl
     }
     if (passes <= 8 && sizeof(T) == 8) {
         if constexpr (sizeof(T) == 8) {
+            // fp64 storage, d = 1000: four rows of 8 packets per sub-batch (64 KB in flight per wave) 143.7 it/s against
+            // round 2's one row per sub-batch with two blocks per CU 136.4-138.6 (RBL_SWEEP_SHAPE=0), two rows 140.5-143.5
             if (shape == 0) return launch_one<T, LOSS, 8, 1, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
-            if (shape == 1) return launch_one<T, LOSS, 8, 2, 4, true>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
-            if (shape == 8) RBL_ONE(8, 4, 4, true);
-            if (shape == 9) RBL_ONE(8, 2, 8, true);
-            if (shape == 10) RBL_ONE(8, 2, 4, true);
-            return launch_one<T, LOSS, 8, 1, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+            RBL_ONE(8, 4, 4, true);
         }
     }
 #undef RBL_ONE
@@ -677,17 +675,18 @@ int launch_T(const T* D, long long n, long long ld, const double* w, const doubl
     const long long pt = (PK + SEW_THREADS - 1) / SEW_THREADS;
     const int wgrid = grid / 2;
     *used = wgrid;
-#define RBL_WIDE(PT_, R_, S_)                                                                                          \
+#define RBL_WIDE(PT_, R_, S_) RBL_WIDE_NT(PT_, R_, S_, SEW_THREADS)
+#define RBL_WIDE_NT(PT_, R_, S_, NT_)                                                                                  \
     do {                                                                                                               \
-        auto kfn = k_sweep_erm_wide<T, LOSS, PT_, R_, S_>;                                                             \
-        const size_t lds = (size_t)PT_ * SEW_THREADS * Pk<T>::E * sizeof(double);                                      \
+        auto kfn = k_sweep_erm_wide<T, LOSS, PT_, R_, S_, NT_>;                                                        \
+        const size_t lds = (size_t)PT_ * NT_ * Pk<T>::E * sizeof(double);                                              \
         static bool attr_set = false;                                                                                  \
         if (!attr_set) {                                                                                               \
             RBL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         (int)lds));                                                                    \
             attr_set = true;                                                                                           \
         }                                                                                                              \
-        hipLaunchKernelGGL(kfn, dim3(wgrid), dim3(SEW_THREADS), lds, s, D, n, ld, w, z_old, lam, v, z_new, sigma0, rho,  \
+        hipLaunchKernelGGL(kfn, dim3(wgrid), dim3(NT_), lds, s, D, n, ld, w, z_old, lam, v, z_new, sigma0, rho,          \
                            pred, slab, partials);                                                                      \
         RBL_HIP(hipGetLastError());                                                                                    \
         return RBL_OK;                                                                                                 \
@@ -696,10 +695,14 @@ int launch_T(const T* D, long long n, long long ld, const double* w, const doubl
     if (pt <= 2) RBL_WIDE(2, 4, 4);
     if (pt <= 3) RBL_WIDE(3, 4, 4);
     if (pt <= 4) RBL_WIDE(4, 2, 8);
+    // (d = 10 000 with workgroups of 4 waves and 10 packets per thread - RBL_WIDE_NT(10, 2, 8, 256), (10, 3, 4, 256) -
+    // runs at 99.8 / 112.3 it/s against 124.6 for this shape at 1.25M x 10000: half of each lane's packets then live in
+    // AGPRs and every use costs a move; profiles/r03_sweep_shapes.txt)
     if (pt <= 5) RBL_WIDE(5, 2, 8);
     if (pt <= 6) RBL_WIDE(6, 1, 16);
     if (pt <= 8) RBL_WIDE(8, 1, 16);
 #undef RBL_WIDE
+#undef RBL_WIDE_NT
     rbl_set_error("single-sweep kernel: d=%lld too wide", (long long)ld);
     return RBL_ERR_INVALID;
 }
