@@ -46,6 +46,7 @@ class RblStats(C.Structure):
         ("ms_z", C.c_float), ("ms_q", C.c_float), ("ms_w", C.c_float), ("ms_v", C.c_float), ("ms_total", C.c_float),
         ("fused", C.c_int32), ("mispredicted", C.c_int32),
         ("fused_v", C.c_int32), ("host_syncs", C.c_int32), ("sort_passes", C.c_int32), ("zband", C.c_int32),
+        ("wstep_form", C.c_int32),
     ]
 
 
@@ -63,6 +64,7 @@ _I64 = C.POINTER(C.c_int64)
 # name -> (restype, argtypes): every symbol include/rbl.h declares
 SIGNATURES = {
     "rbl_version": (C.c_int, []),
+    "rbl_sizeof": (C.c_int, [C.c_int]),
     "rbl_last_error": (C.c_char_p, []),
     "rbl_device_count": (C.c_int, []),
     "rbl_create": (C.c_int, [C.POINTER(RblConfig), C.POINTER(_P)]),
@@ -182,6 +184,10 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        for which, cls in ((0, RblConfig), (1, RblStats)):
+            if lib.rbl_sizeof(which) != C.sizeof(cls):
+                raise ImportError(f"{LIB_PATH}: sizeof({cls.__name__}) is {lib.rbl_sizeof(which)} in the library and "
+                                  f"{C.sizeof(cls)} in this binding (include/rbl.h and _lib.py out of step: rebuild)")
         _lib = lib
     return _lib
 

@@ -562,6 +562,8 @@ extern "C" {
 
 int rbl_version(void) { return RBL_VERSION; }
 
+int rbl_sizeof(int which) { return which == 0 ? (int)sizeof(rbl_config) : which == 1 ? (int)sizeof(rbl_stats) : -1; }
+
 const char* rbl_last_error(void) { return g_err.c_str(); }
 
 int rbl_device_count(void) {
@@ -1319,6 +1321,7 @@ int rbl_phase_w_external(rbl_solver* h, const double* w) {
     h->z_ready = false;        // (a caller that skipped rbl_phase_q: nothing of a previous pass is pending any more)
     h->v_valid = false;
     h->inner_iters = 0;
+    h->ww.form = -1;
     if (h->phase_timing) RBL_HIP(hipEventRecord(h->ev[3], h->stream));
     return RBL_OK;
 }
@@ -1638,6 +1641,7 @@ int rbl_phase_finish(rbl_solver* h, rbl_stats* out) {
         out->host_syncs = g_host_syncs;    // stream waits, blocking copies and spins since the last rbl_phase_finish
         out->sort_passes = h->sorted_path ? h->sort_passes : -1;
         out->zband = h->sorted_path ? h->zb.mode : -1;
+        out->wstep_form = h->ww.form;
     }
     h->rho = rho_next;
     h->iter = i + 1;

@@ -536,6 +536,7 @@ int run_ncg(const double* G, int64_t ld, const double* q, double rho, double reg
             if (status == 1) {
                 ws.last_fista = it;
                 ws.gw_valid = want_Gw;
+                ws.form = 1;
                 if (iters_host) *iters_host = it;
                 return RBL_OK;
             }
@@ -1146,6 +1147,7 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
               bool* fs_pending, const double* rho_dev, double* w_prev_out, bool want_Gw) {
     if (fs_pending) *fs_pending = false;
     ws.gw_valid = false;
+    ws.form = 0;
     if (ld > (long long)UPD_THREADS * UPD_PER) {
         rbl_set_error("w-step: d=%lld exceeds the single-block update limit %d", (long long)ld, UPD_THREADS * UPD_PER);
         return RBL_ERR_INVALID;
@@ -1154,6 +1156,7 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
         // (rho G + reg I) w = rho q through the one-time eigendecomposition of G (eig.hip): two mat-vecs for any rho,
         // plus one step of iterative refinement against G itself
         if (iters_host) *iters_host = 1;
+        ws.form = 3;
         return launch_ridge_eig(G, ws.eig_Vt, ws.eig_V, ws.eig_lambda, ld, q, rho, reg, w, ws.Gy, ws.r, s);
     }
     if (wstep == RBL_WSTEP_L2) {
@@ -1169,6 +1172,7 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
             }
             if (status == 1) ws.last_iters = it;
             ws.gw_valid = want_Gw;
+            ws.form = 1;
             if (iters_host) *iters_host = it;
             return RBL_OK;
         }
@@ -1209,6 +1213,7 @@ int run_wstep(int wstep, const double* G, int64_t ld, const double* q, double rh
         // its capacity (e.g. the dense initial w of algorithms.py:42) or it hits its cap.  The
         // kernel writes its status block straight into pinned host memory.
         ws.pin[0] = -1;   // sentinel: the kernel stores its status (>= 0) here last
+        ws.form = 2;
         RBL_TRY(launch_lasso_fs(G, ld, ld, q, w, reg / (2.0 * rho), ws.pin, s, rho_dev, reg, w_prev_out,
                                 want_Gw ? ws.Gy : nullptr));
         if (fs_pending) {
@@ -1236,6 +1241,7 @@ int finish_wstep_l1(const double* G, int64_t ld, const double* q, double rho, do
         return RBL_OK;
     }
     if (fell_back) *fell_back = true;
+    ws.form = 0;
     return run_fista(0, G, ld, q, rho, reg, 1.0, L, tol, max_inner, w, ws, iters_host, s);
 }
 

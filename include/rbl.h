@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RBL_VERSION 105
+#define RBL_VERSION 106
 
 /* status codes */
 enum {
@@ -100,12 +100,19 @@ typedef struct rbl_stats {
     int32_t sort_passes;     /* radix-sort passes the z-step executed (digits shared by all keys are skipped), -1 = n/a */
     int32_t zband;           /* rank-weighted z-step: 0 = sort + merge-tree PAV, 1 = sort-free banded path (piecewise-constant
                                 weights), 2 = banded path not certified, redone with the sort; -1 = n/a */
+    int32_t wstep_form;      /* how the w-step ran: 0 = batches of launches (CG / nonlinear CG / FISTA), 1 = ONE persistent
+                                launch (k_cg_persist / k_ncg_persist), 2 = the exact active-set lasso kernel, 3 = the
+                                eigen-decomposition ridge, -1 = an overridden w_subproblem (rbl_phase_w_external) */
 } rbl_stats;
 
 typedef struct rbl_solver rbl_solver;
 
 /* ---- lifetime ------------------------------------------------------------------ */
 int  rbl_version(void);
+/* sizeof(rbl_config) (which = 0) / sizeof(rbl_stats) (which = 1) as THIS library was compiled: a binding whose
+ * structure definitions are older or newer than the library checks them at load time instead of letting rbl_step
+ * write past its buffer; -1 for any other `which` */
+int  rbl_sizeof(int which);
 const char* rbl_last_error(void);
 int  rbl_device_count(void);
 /* Optimizer.__init__ / rankbasedObjective.__init__ */

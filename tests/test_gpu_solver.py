@@ -59,6 +59,8 @@ def test_iterates_match_oracle_exact(R, name, kw):
         assert abs(st.objective - ref.objective[i + 1]) <= tol * max(1.0, abs(ref.objective[i + 1])), (name, i)
         if kw["weight_function"] == "ehrm":
             assert st.ehrm_branch == (0 if ref.branch[i] == "a" else 1)
+        if "l2_reg" in kw:
+            assert st.wstep_form == 1, (name, i, st.wstep_form)     # the CG as ONE persistent launch (k_cg_persist)
     state = s._s.get_state()
     scale = max(1.0, np.max(np.abs(ref.z)))
     assert np.max(np.abs(state["w"] - ref.w)) <= tol * max(1.0, np.max(np.abs(ref.w)))
@@ -84,6 +86,7 @@ def test_sadmm_iterates_match_oracle_exact(R, n, d, t0):
     for i in range(nit):
         st = s._s.step(want_objective=True)
         inner.append(st.inner_iters)
+        assert st.wstep_form == 1, (i, st.wstep_form)               # the nonlinear CG as ONE persistent launch (k_ncg_persist)
         assert abs(st.rho - ref.rho[i]) <= 1e-15 * ref.rho[i]
         assert abs(st.primal - ref.primal[i]) <= 1e-8 * max(1.0, ref.primal[i]), (i, st.primal, ref.primal[i])
         assert abs(st.dual - ref.dual[i]) <= 1e-8 * max(1.0, ref.dual[i]), (i, st.dual, ref.dual[i])
@@ -97,6 +100,44 @@ def test_sadmm_iterates_match_oracle_exact(R, n, d, t0):
     assert np.count_nonzero(w_final) == np.count_nonzero(ref.w)
     assert np.max(np.abs(state["z"] - ref.z)) <= 1e-7 * max(1.0, np.max(np.abs(ref.z)))
     assert np.max(np.abs(state["lam"] - ref.lam)) <= 1e-7 * max(1e-3, np.max(np.abs(ref.lam)))
+
+
+@pytest.mark.parametrize("smooth", [False, True], ids=["cg_ridge", "ncg_smoothed_l1"])
+def test_wstep_persistent_and_batched_forms_agree(R, smooth):
+    """The d-space w-steps run as ONE persistent launch while the process holds a single solver handle on the device,
+    and as batches of launches as soon as a second handle is alive (two persistent kernels side by side could each hold
+    CUs the other waits for; csrc/wstep.hip wp_plan).  rbl_stats.wstep_form says which form ran; both solve the same
+    sub-problem (w_LBFGS.py:11-62 / algorithms.py:108-120) to ~1e-13, so the iterates agree to 1e-9."""
+    from oracle import problems
+    X, y = problems.make_problem(3000, 160, seed=5)
+    nit = 30
+    if smooth:
+        make = lambda: R.smoothADMMmethod(X, y, max_iter=nit, tol=0.0, storage="f64", weight_function="erm",
+                                          loss="binary_cross_entropy", l1_reg=0.01)
+    else:
+        make = lambda: R.ADMMmethod(X, y, max_iter=nit, tol=0.0, storage="f64", weight_function="superquantile",
+                                    loss="binary_cross_entropy", l2_reg=0.01, args=[0.5])
+
+    def run(s):
+        forms, rows = set(), []
+        for _ in range(nit):
+            st = s._s.step(want_objective=True)
+            forms.add(st.wstep_form)
+            rows.append((st.primal, st.dual, st.objective))
+        return forms, np.array(rows), s._s.get_state()["w"]
+
+    a = make()
+    forms_a, rows_a, w_a = run(a)
+    a._s.close()
+    assert forms_a == {1}, forms_a
+    other = make()                      # a second live handle of this process on the device
+    b = make()
+    forms_b, rows_b, w_b = run(b)
+    other._s.close()
+    b._s.close()
+    assert forms_b == {0}, forms_b
+    assert np.max(np.abs(rows_a - rows_b) / np.maximum(1.0, np.abs(rows_a))) <= 1e-9
+    assert np.max(np.abs(w_a - w_b)) <= 1e-9 * max(1.0, np.max(np.abs(w_a)))
 
 
 def test_f32_storage_close_to_f64(R):

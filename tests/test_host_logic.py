@@ -5,6 +5,7 @@ consistent, and the multi-GPU driver (one process per GPU) gives shard-count-inv
 iterates - exercised with world_size 2 over gloo and a NumPy engine built on the oracle."""
 import os
 import re
+import ctypes as C
 import sys
 
 import numpy as np
@@ -29,7 +30,26 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # the Python binding covers the same set
     assert declared == set(rbl._lib.SIGNATURES), declared ^ set(rbl._lib.SIGNATURES)
-    assert lib.rbl_version() == 105
+    assert lib.rbl_version() == 106
+
+
+def test_structure_layouts_agree_with_the_library():
+    """rbl_step writes sizeof(rbl_stats) bytes into the caller's buffer: the ctypes mirrors - the package's and the
+    stub INTEGRATION.md shows a maintainer - must have the library's sizes (rbl_sizeof) and the header's field names."""
+    rbl = _pkg()
+    lib = rbl._lib.load()
+    assert lib.rbl_sizeof(0) == C.sizeof(rbl._lib.RblConfig) and lib.rbl_sizeof(1) == C.sizeof(rbl._lib.RblStats)
+    assert lib.rbl_sizeof(7) == -1
+    header = open(os.path.join(ROOT, "include", "rbl.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for struct, cls in (("rbl_config", rbl._lib.RblConfig), ("rbl_stats", rbl._lib.RblStats)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = [n.strip().split("[")[0] for decl in re.findall(r"(?:int64_t|int32_t|double|float)\s+([^;]+);", body)
+                 for n in decl.split(",")]
+        assert names == [f[0] for f in cls._fields_], (struct, names)
+        stub = re.search(r"class %s\(C\.Structure\):.*?_fields_ = \[(.*?)\]\n" % struct, doc, re.S).group(1)
+        assert re.findall(r'\("([a-z_A-Z0-9]+)",', stub) == names, struct
 
 
 def test_no_cpu_fallback_without_device():
