@@ -333,15 +333,16 @@ __global__ __launch_bounds__(SE_THREADS, OCC) void k_sweep_erm(
     }
 }
 
-// ---- wide rows (more than 4 x 64 packets, e.g. d = 10 000): one WORKGROUP of 8 waves per row
-// batch.  Thread t owns packets t, t+512, ... of every row (PT packets), so w and the column
-// sums stay in registers exactly as in the wave-per-row kernel; the dot product is folded
-// across the 8 waves through LDS (fixed order), the owner lane of each row does the row-wise
-// update + prox, and the coefficients come back through LDS: two workgroup barriers per batch
-// of R rows, hidden behind the next batch's loads already in flight.  Same super-batches of
-// S*R = 16 consecutive rows, same arithmetic per row, one slab row per workgroup.  w lives in
-// LDS ([p][thread][k], up to 128 KB: one workgroup per CU), which leaves the registers to the two
-// row buffers and the column sums.
+// ---- wide rows (more than 8 x 64 packets, e.g. d = 10 000): one WORKGROUP of 8 waves per row
+// batch.  Thread t owns packets t, t+512, ... of every row (PT packets), so the column sums stay in
+// registers exactly as in the wave-per-row kernel; the dot product is folded across the 8 waves
+// through LDS (fixed order), the owner lane of each row does the row-wise update + prox, and the
+// coefficients come back through LDS: two workgroup barriers per batch of R rows, hidden behind the
+// next batch's loads already in flight.  Super-batches of S*R consecutive rows (16-24), same arithmetic
+// per row, one slab row per workgroup.  w lives in LDS ([p][thread][k], up to 128 KB: one workgroup per
+// CU) and so do the row-wise values of the super-batch in flight (z_old, lambda, the three outputs and the
+// two running sums of each row's owner thread), which leaves the registers to the two row buffers and
+// the column sums: R is the largest number of rows whose two buffers fit (launch_T).
 constexpr int SEW_THREADS = 512;
 
 template <typename T, int LOSS, int PT, int R, int S, int NT = SEW_THREADS>
@@ -356,9 +357,8 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_erm_wide(
     const unsigned row_bytes = (unsigned)ld * (unsigned)sizeof(T);
     const double rho_next = pred[0];
 
-    extern __shared__ __align__(16) double sw_wide[];   // PT * 512 * E doubles
+    extern __shared__ __align__(16) double sw_wide[];   // PT * NT * E doubles
     double acc[PT][E];
-    int boff[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
         int pkp = tid + NT * p;
@@ -368,11 +368,13 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_erm_wide(
             sw_wide[(p * NT + tid) * E + k] = ok ? w[(long long)pkp * E + k] : 0.0;
             acc[p][k] = 0.0;
         }
-        // packets past the row end: an offset outside the row descriptor - the range check returns 0
-        // without a memory access (w == 0 there and the column sums are dropped)
-        boff[p] = ok ? pkp * 16 : 0x7ffffff0;
     }
-    double s_prim = 0.0, s_zz = 0.0;   // (each thread reads back only what it wrote: no barrier needed for sw_wide)
+    // Per-lane byte offsets of the packets inside a row: tid * 16 + p * NT * 16 - one VGPR and an immediate per packet.
+    // Only the LAST packet group can reach past the row end (PK > (PT - 1) * NT by the choice of PT): its lanes past the
+    // end use an offset outside the row descriptor - the range check returns 0 without a memory access (w == 0 there
+    // and the column sums are dropped).
+    const int voff = tid * 16;
+    const int voff_last = (tid + NT * (PT - 1) < PK) ? voff + NT * (PT - 1) * 16 : 0x7ffffff0;
 
     constexpr int SR = S * R;
     const int nsuper = (int)((n + SR - 1) / SR);
@@ -381,6 +383,16 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_erm_wide(
 
     __shared__ double part[NW][R];   // per-wave partial dot products of the batch
     __shared__ double cshare[R];     // coefficients of the batch's rows
+    // Row-wise values of the super-batch in flight, one slot per row, written and read by the SAME thread (thread i < SR
+    // owns row i of the super-batch, so no synchronisation): registers moved to LDS by hand - z_old and lambda of the
+    // row, its three outputs and the thread's two running sums, 14 VGPRs.  At d = 10 000 that is what lets a THIRD row per
+    // sub-batch fit without a spill (three rows of 5 packets in flight per wave instead of two: C5shard 124.6 -> 132
+    // it/s); the LDS round trips on the owner's path between the two barriers cost ~1.5 % at equal R.
+    __shared__ double rw_zo[SR], rw_lm[SR], rw_l[SR], rw_v[SR], rw_z[SR], rw_prim[SR], rw_zz[SR];
+    if (tid < SR) {
+        rw_prim[tid] = 0.0;
+        rw_zz[tid] = 0.0;
+    }
 
     auto load_side = [&](int q, double& zo, double& lm) {
         const int live = q == nsuper - 1 ? live_last : SR;
@@ -399,12 +411,12 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_erm_wide(
             const __amdgpu_buffer_rsrc_t rs =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(D + row * ld), 0, (int)row_bytes, 0x00020000);
 #pragma unroll
-            for (int p = 0; p < PT; ++p) buf[r][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[p], 0, RBL_D_AUX);
+            for (int p = 0; p < PT; ++p)
+                buf[r][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, p == PT - 1 ? voff_last : voff + NT * p * 16, 0, RBL_D_AUX);
         }
     };
 
-    double l_out = 0.0, v_out = 0.0, z_out = 0.0;
-    auto process = [&](int live, int sub, u32x4 (&buf)[R][PT], double zo, double lm) {
+    auto process = [&](int live, int sub, u32x4 (&buf)[R][PT]) {
         double dot[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) dot[r] = 0.0;
@@ -432,16 +444,17 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_erm_wide(
             double myv = 0.0;
 #pragma unroll
             for (int wv = 0; wv < NW; ++wv) myv += part[wv][r];
+            const double zo = rw_zo[tid];
             const double res = zo - myv;
-            const double l = lm + rho * res;                       // algorithms.py:132
-            s_prim += res * res;                                   // algorithms.py:135
+            const double l = rw_lm[tid] + rho * res;               // algorithms.py:132
+            rw_prim[tid] += res * res;                             // algorithms.py:135
             const double lr = l / rho_next;
             const double m = myv - lr;                             // algorithms.py:89 (next iteration)
             const double zn = (LOSS == 0) ? rbl::prox_bce_warm(sigma0, rho_next, m, zo) : rbl::prox_hinge(sigma0, rho_next, m);
-            s_zz += zn * zn;
-            l_out = l;
-            v_out = myv;
-            z_out = zn;
+            rw_zz[tid] += zn * zn;
+            rw_l[tid] = l;
+            rw_v[tid] = myv;
+            rw_z[tid] = zn;
             c = zn + lr;
         }
         if (tid >= sub * R && tid < sub * R + R) cshare[tid - sub * R] = c;   // 0 for rows past n
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_erm_wide(
     // NEXT sub-batch is requested into bufB, and the arithmetic runs on bufA, whose registers are
     // never the target of a load (so nothing in process() waits for the prefetch in flight).
     u32x4 bufA[R][PT], bufB[R][PT];
-    double zo = 0.0, lm = 0.0, zoN = 0.0, lmN = 0.0;
+    double zoN = 0.0, lmN = 0.0;
     int q = (int)blockIdx.x, sub = 0;
     if (q < nsuper) {
         load_side(q, zoN, lmN);
@@ -476,9 +489,9 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_erm_wide(
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int p = 0; p < PT; ++p) bufA[r][p] = bufB[r][p];
-        if (sub == 0) {
-            zo = zoN;
-            lm = lmN;
+        if (sub == 0 && tid < SR) {
+            rw_zo[tid] = zoN;
+            rw_lm[tid] = lmN;
         }
         const bool last = sub + 1 == S;
         const int qn = last ? q + GW : q;
@@ -489,18 +502,19 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_erm_wide(
             load_rows(qn, subn, bufB);
         }
         __builtin_amdgcn_sched_barrier(0);   // the prefetch stays above the arithmetic
-        process(live, sub, bufA, zo, lm);
+        process(live, sub, bufA);
         if (last) {
             if (tid < live) {
                 const long long row = (long long)q * SR + tid;
-                row_store<0>(lam, row, l_out);
-                if (v) row_store<0>(v, row, v_out);   // NULL: nobody reads v before the next pass (no objective logging)
-                row_store<0>(z_new, row, z_out);
+                row_store<0>(lam, row, rw_l[tid]);
+                if (v) row_store<0>(v, row, rw_v[tid]);   // NULL: nobody reads v before the next pass (no objective logging)
+                row_store<0>(z_new, row, rw_z[tid]);
             }
         }
         q = qn;
         sub = subn;
     }
+    const double s_prim = tid < SR ? rw_prim[tid] : 0.0, s_zz = tid < SR ? rw_zz[tid] : 0.0;
 
     // every thread owns its columns: the slab row of this workgroup is written directly
 #pragma unroll
@@ -662,11 +676,16 @@ int launch_T(const T* D, long long n, long long ld, const double* w, const doubl
         if (shape == 8) RBL_ONE(4, 8, 2, true);
         RBL_ONE(4, 4, 4, true);
     }
-    if (passes <= 8 && sizeof(T) == 8) {
+    if (passes <= 8) {
+        // 5-8 packets per lane and row (fp64 storage d <= 1024, fp32 storage d <= 2048).  fp64, d = 1000: four rows of 8
+        // packets per sub-batch (64 KB in flight per wave) 143.7 it/s against round 2's one row per sub-batch with two
+        // blocks per CU 136.4-138.6 (RBL_SWEEP_SHAPE=0), two rows 140.5-143.5.  fp32 storage took the workgroup-per-row
+        // kernel from d = 1025 on until round 3 (4M x 2000: 171.8 it/s, 5.5 TB/s); RBL_SWEEP_SHAPE=0 keeps that.
         if constexpr (sizeof(T) == 8) {
-            // fp64 storage, d = 1000: four rows of 8 packets per sub-batch (64 KB in flight per wave) 143.7 it/s against
-            // round 2's one row per sub-batch with two blocks per CU 136.4-138.6 (RBL_SWEEP_SHAPE=0), two rows 140.5-143.5
             if (shape == 0) return launch_one<T, LOSS, 8, 1, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+        }
+        if (sizeof(T) == 8 || shape != 0) {
+            if (shape == 9) RBL_ONE(8, 2, 8, true);
             RBL_ONE(8, 4, 4, true);
         }
     }
@@ -691,16 +710,38 @@ int launch_T(const T* D, long long n, long long ld, const double* w, const doubl
         RBL_HIP(hipGetLastError());                                                                                    \
         return RBL_OK;                                                                                                 \
     } while (0)
-    if (pt <= 1) RBL_WIDE(1, 16, 1);
-    if (pt <= 2) RBL_WIDE(2, 4, 4);
-    if (pt <= 3) RBL_WIDE(3, 4, 4);
-    if (pt <= 4) RBL_WIDE(4, 2, 8);
-    // (d = 10 000 with workgroups of 4 waves and 10 packets per thread - RBL_WIDE_NT(10, 2, 8, 256), (10, 3, 4, 256) -
-    // runs at 99.8 / 112.3 it/s against 124.6 for this shape at 1.25M x 10000: half of each lane's packets then live in
-    // AGPRs and every use costs a move; profiles/r03_sweep_shapes.txt)
-    if (pt <= 5) RBL_WIDE(5, 2, 8);
-    if (pt <= 6) RBL_WIDE(6, 1, 16);
-    if (pt <= 8) RBL_WIDE(8, 1, 16);
+    // Rows per sub-batch: as many as the 256 registers of a wave (8 waves per workgroup, one workgroup per CU) hold in two
+    // buffers beside the column sums - the pass is bound by the bytes each wave keeps in flight.  fp32 storage, 30-32 GB
+    // per pass, it/s (profiles/r03_sweep_shapes.txt):  d = 4000: 4 rows 177.5, 6 rows 196.5, 8 rows 204.1;  d = 6000:
+    // 4 rows 203.2, 5 rows 208.0, 6 rows 210.6;  d = 8000: 2 rows 178.7, 3 rows 200.4, 4 rows 209.8;  d = 10 000: 1 row
+    // 80.0, 2 rows 124.6, 3 rows 132.3 (4 rows spill: 68);  d = 12 000: 1 row 130.7, 2 rows 200.6;  d = 16 000: 1 row
+    // 147.1 (two spill).  RBL_WIDE_SHAPE=2: round 2's shapes.
+    static const int wshape = [] {
+        const char* e = getenv("RBL_WIDE_SHAPE");
+        return e ? atoi(e) : 0;
+    }();
+    if (pt <= 1) RBL_WIDE(1, 16, 1);   // (fp32 storage reaches this kernel from 9 packets per lane on: pt >= 2)
+    if (pt <= 2) {
+        if (wshape == 2) RBL_WIDE(2, 4, 4);
+        RBL_WIDE(2, 8, 2);
+    }
+    if (pt <= 3) {
+        if (wshape == 2) RBL_WIDE(3, 4, 4);
+        RBL_WIDE(3, 6, 4);
+    }
+    if (pt <= 4) {
+        if (wshape == 2) RBL_WIDE(4, 2, 8);
+        RBL_WIDE(4, 4, 4);
+    }
+    if (pt <= 5) {
+        if (wshape == 2) RBL_WIDE(5, 2, 8);
+        RBL_WIDE(5, 3, 8);
+    }
+    if (pt <= 6) {
+        if (wshape == 2) RBL_WIDE(6, 1, 16);
+        RBL_WIDE(6, 2, 8);
+    }
+    if (pt <= 8) RBL_WIDE(8, 1, 16);   // (two rows spill with fp32 storage)
 #undef RBL_WIDE
 #undef RBL_WIDE_NT
     rbl_set_error("single-sweep kernel: d=%lld too wide", (long long)ld);
@@ -715,12 +756,6 @@ bool sweep_erm_supported(int storage, int64_t ld) {
     // kernel up to 8 packets per thread: d <= 16384 (fp32) / 8192 (fp64)
     return PK > 32 && PK <= 8 * SEW_THREADS;
 }
-// the wide kernel runs one workgroup per CU and reports its slab rows / partials as such
-static bool sweep_erm_is_wide(int storage, int64_t ld) {
-    const int64_t PK = ld / (storage == RBL_STORE_F32 ? 4 : 2);
-    return PK > (storage == RBL_STORE_F32 ? 256 : 512);
-}
-
 // upper bound of the blocks a single-sweep launch uses (slab rows, partial triples): 2 per CU; the shapes that run one
 // block per CU (launch_T) use the first half
 int sweep_erm_blocks(int num_cu) { return num_cu * 2; }
@@ -787,9 +822,10 @@ int launch_v_T(const T* D, long long n, long long ld, const double* w, const dou
                double* partials, int grid, hipStream_t s) {
     const long long PK = ld / Pk<T>::E;
     const long long passes = (PK + 63) / 64;
-#define RBL_V(P_, R_, S_)                                                                                           \
+#define RBL_V(P_, R_, S_) RBL_V2(P_, R_, S_, false, 2)
+#define RBL_V2(P_, R_, S_, WL_, OCC_)                                                                               \
     do {                                                                                                            \
-        hipLaunchKernelGGL((k_sweep_erm<T, 1, P_, R_, S_, false, SE_VONLY, true>), dim3(grid), dim3(SE_THREADS), 0, s, D, n, \
+        hipLaunchKernelGGL((k_sweep_erm<T, 1, P_, R_, S_, WL_, SE_VONLY, true, OCC_>), dim3(grid), dim3(SE_THREADS), 0, s, D, n, \
                            ld, w, z, lam, v, (double*)nullptr, 0.0, rho, (const double*)nullptr, (double*)nullptr,  \
                            partials);                                                                               \
         RBL_HIP(hipGetLastError());                                                                                 \
@@ -798,10 +834,11 @@ int launch_v_T(const T* D, long long n, long long ld, const double* w, const dou
     if (passes == 1) RBL_V(1, 8, 2);
     if (passes == 2) RBL_V(2, 4, 4);
     if (passes <= 4) RBL_V(4, 2, 8);   // (four rows per sub-batch: no gain here, 3.50 against 3.46-3.50 ms at 6M x 1000)
-    if constexpr (sizeof(T) == 8) {
-        if (passes <= 8) RBL_V(8, 1, 8);
-    }
+    // 5-8 packets per lane (fp64 d <= 1024, fp32 d <= 2048): two rows per sub-batch, w in LDS, the one block per CU may
+    // use up to 512 registers per lane
+    if (passes <= 8) RBL_V2(8, 2, 8, true, 1);
 #undef RBL_V
+#undef RBL_V2
     return RBL_ERR_INVALID;
 }
 }  // namespace
@@ -810,7 +847,7 @@ int launch_v_T(const T* D, long long n, long long ld, const double* w, const dou
 // (replaces k_gemv + k_dual when the row width fits the wave-per-row kernel)
 bool sweep_v_supported(int storage, int64_t ld) {
     const int64_t PK = ld / (storage == RBL_STORE_F32 ? 4 : 2);
-    return PK > 32 && PK <= (storage == RBL_STORE_F32 ? 256 : 512);
+    return PK > 32 && PK <= 512;
 }
 
 int launch_sweep_v(int storage, const void* D, int64_t n, int64_t ld, const double* w, const double* z, double* lam,
@@ -840,9 +877,10 @@ template <typename T>
 int launch_q_T(const T* D, long long n, long long ld, const double* c, double* slab, int grid, hipStream_t s) {
     const long long PK = ld / Pk<T>::E;
     const long long passes = (PK + 63) / 64;
-#define RBL_Q(P_, R_, S_)                                                                                            \
+#define RBL_Q(P_, R_, S_) RBL_Q2(P_, R_, S_, 2)
+#define RBL_Q2(P_, R_, S_, OCC_)                                                                                     \
     do {                                                                                                             \
-        hipLaunchKernelGGL((k_sweep_erm<T, 1, P_, R_, S_, false, SE_QONLY, true>), dim3(grid), dim3(SE_THREADS), 0, s, D, n,  \
+        hipLaunchKernelGGL((k_sweep_erm<T, 1, P_, R_, S_, false, SE_QONLY, true, OCC_>), dim3(grid), dim3(SE_THREADS), 0, s, D, n,  \
                            ld, (const double*)nullptr, c, (double*)nullptr, (double*)nullptr, (double*)nullptr, 0.0, 1.0,     \
                            (const double*)nullptr, slab, (double*)nullptr);                                          \
         RBL_HIP(hipGetLastError());                                                                                  \
@@ -851,10 +889,9 @@ int launch_q_T(const T* D, long long n, long long ld, const double* c, double* s
     if (passes == 1) RBL_Q(1, 8, 2);
     if (passes == 2) RBL_Q(2, 4, 4);
     if (passes <= 4) RBL_Q(4, 2, 8);
-    if constexpr (sizeof(T) == 8) {
-        if (passes <= 8) RBL_Q(8, 1, 8);
-    }
+    if (passes <= 8) RBL_Q2(8, 2, 8, 1);
 #undef RBL_Q
+#undef RBL_Q2
     return RBL_ERR_INVALID;
 }
 }  // namespace
