@@ -663,6 +663,7 @@ def test_single_sweep_paths(loss, reg_kind):
     (17, 2300, "f64", "hinge", "l2_reg"),                    # one full super-batch + 1 row
     (3, 260, "f32", "binary_cross_entropy", "l1_reg"),       # 3 rows, wave-per-row kernel
     (33, 520, "f64", "binary_cross_entropy", "l2_reg"),      # 2 super-batches + 1 row
+    (300, 2048, "f32", "hinge", "l1_reg"),                   # the widest row of the wave-per-row kernel (fp32: 8 packets per lane)
     (7, 9000, "f32", "binary_cross_entropy", "l1_reg"),      # 5 packets per thread (C5's kernel): fewer rows than one sub-batch row set
     (49, 10000, "f32", "hinge", "l2_reg"),                   # C5's width: one super-batch of 48 rows + 1 row
 ])

@@ -52,6 +52,8 @@ WIDTHS = [
     ("ehrm", 3000, 140, False, "f32"),
     ("ehrm", 2999, 520, False, "f32"),
     ("extremile_l1", 3001, 333, False, "f32"),  # padded columns (d % 4 != 0), lasso w-step
+    ("superq", 3001, 1500, False, "f32"),     # fp32 P=8 (round 3: fp32 storage up to d = 2048 on the wave-per-row kernel)
+    ("ehrm", 1999, 2048, False, "f32"),       # ... its largest width
 ]
 
 
