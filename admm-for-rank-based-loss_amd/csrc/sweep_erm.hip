@@ -646,8 +646,6 @@ int launch_T(const T* D, long long n, long long ld, const double* w, const doubl
     const long long PK = ld / Pk<T>::E;
     const long long passes = (PK + 63) / 64;
     *used = grid;
-    if (passes == 1) return launch_one<T, LOSS, 1, 8, 2, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
-    if (passes == 2) return launch_one<T, LOSS, 2, 4, 4, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
     // 3-4 (fp64 storage: 5-8) packets per lane: ONE block of 4 waves per CU, four (two) rows per sub-batch and two
     // sub-batch buffers - 32 KB of loads in flight per wave - with w in LDS.  Round 2's shape (two rows per sub-batch,
     // two blocks per CU, w in registers) is 5 % slower at 6M x 1000 and ramps over its first ~25 launches after an idle
@@ -670,6 +668,18 @@ int launch_T(const T* D, long long n, long long ld, const double* w, const doubl
         return launch_one<T, LOSS, P_, R_, S_, WL_, 1>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, \
                                                        num_cu * bpc1, s);                                                     \
     } while (0)
+    // 1 and 2 packets per lane (fp32 storage: d <= 256 / 512).  One packet: the per-row work (wave reduction, prox on one
+    // lane) weighs most, more waves hide it - 16 rows per sub-batch, still two blocks per CU: 24M x 250 201.5 -> 224 it/s
+    // (one block per CU: 184-189).  Two packets: 8 rows per sub-batch, super-batches of 64 rows (512-byte row-wise
+    // segments), one block per CU: 12M x 500 255.5 -> 269 (profiles/r03_sweep_shapes.txt block 8).
+    if (passes == 1) {
+        if (shape == 0) return launch_one<T, LOSS, 1, 8, 2, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+        return launch_one<T, LOSS, 1, 16, 2, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+    }
+    if (passes == 2) {
+        if (shape == 0) return launch_one<T, LOSS, 2, 4, 4, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
+        RBL_ONE(2, 8, 8, false);
+    }
     if (passes <= 4) {
         if (shape == 0) return launch_one<T, LOSS, 4, 2, 8, false>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
         if (shape == 1) return launch_one<T, LOSS, 4, 4, 4, true>(D, n, ld, w, z_old, lam, v, z_new, sigma0, rho, pred, slab, partials, grid, s);
