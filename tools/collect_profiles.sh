@@ -12,6 +12,8 @@ python3 tools/traffic_from_pmc.py "$(find "$OUT/pmc_fetch" -name 'f_counter_coll
     "$(find "$OUT/pmc_write" -name 'w_counter_collection.csv' | head -1)" 6000000 1000 f32 "${TAG}_C2_fused"
 cp "$(find "$OUT/c2sq" -name 'c2sq_kernel_stats.csv' | head -1)" "profiles/${TAG}_C2sq_kernel_stats.csv"
 python3 tools/lds_from_pmc.py "$(find "$OUT/pmc_lds" -name 'l_counter_collection.csv' | head -1)" "${TAG}_C2sq"
+f=$(find "$OUT/pmc_lds_c4" -name 'l_counter_collection.csv' 2>/dev/null | head -1)
+[ -n "$f" ] && python3 tools/lds_from_pmc.py "$f" "${TAG}_C4shard"
 for cfg in C3 C4shard C5shard; do
     f=$(find "$OUT/$cfg" -name 'x_kernel_stats.csv' | head -1)
     [ -n "$f" ] && cp "$f" "profiles/${TAG}_${cfg}_kernel_stats.csv"

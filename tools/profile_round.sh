@@ -35,6 +35,12 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVES SQ_
 python3 tools/lds_from_pmc.py "$(find "$OUT/pmc_lds" -name 'l_counter_collection.csv' | head -1)" "${TAG}_C2sq"
 echo "[5/5] LDS PMC pass done"
 
+# the same counters where the z-step runs sort + PAV in EVERY iteration (EHRM: 32-bit radix sort, both PAV kernels)
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS \
+    --kernel-trace --output-format csv -d "$OUT/pmc_lds_c4" -o l -- python3 $B --config C4shard --steps 5 > "$OUT/l4.log" 2>&1
+python3 tools/lds_from_pmc.py "$(find "$OUT/pmc_lds_c4" -name 'l_counter_collection.csv' | head -1)" "${TAG}_C4shard"
+echo "[5b] LDS PMC pass of C4shard done"
+
 # kernel stats of the other BASELINE configurations that fit one GPU (no PMC passes)
 for cfg in C3 C4shard C5shard; do
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$cfg" -o x -- python3 $B --config $cfg --steps 10 > "$OUT/$cfg.log" 2>&1
