@@ -570,9 +570,12 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
         if (SPEC) {
             double x = 0.0;
             if (ok) {
-                const double m = lm[k], sm = rbl::sigmoid1(m);
+                // one exponential serves sigmoid(m) and softplus(m); the two objective values are expanded around m
+                // (device_math.h: softplus_near), the two prox problems start from the O(a^4) estimate
+                const double m = lm[k], em = exp(-fabs(m)), inv = 1.0 / (1.0 + em);
+                const double sm = (m > 0.0) ? inv : em * inv, spm = fmax(m, 0.0) + log1p(em);
                 x = rbl::prox_bce_est(ls[k], rho, m, sm);                    // level 0 of the speculated branch
-                const double so = (use_b ? sa : sb)[base + i];               // the other branch's weight
+                const double so = (use_b ? sa : sb)[base + i];               // the weight of the other branch
                 // speculated branch: clipped at B from its own side; other branch: B itself wherever its prox lies beyond B
                 double os = x, oo;
                 if (use_b) {
@@ -582,8 +585,8 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
                     if (os > B) os = B;
                     oo = (m <= B + so * sigB / rho) ? B : fmax(rbl::prox_bce_est(so, rho, m, sm), B);
                 }
-                const double fs = ls[k] * (os == B ? spB : rbl::softplus(os)) + 0.5 * rho * (os - m) * (os - m);
-                const double fo = so * (oo == B ? spB : rbl::softplus(oo)) + 0.5 * rho * (oo - m) * (oo - m);
+                const double fs = ls[k] * (os == B ? spB : rbl::softplus_near(os, m, spm, sm)) + 0.5 * rho * (os - m) * (os - m);
+                const double fo = so * (oo == B ? spB : rbl::softplus_near(oo, m, spm, sm)) + 0.5 * rho * (oo - m) * (oo - m);
                 f12[use_b ? 1 : 0] += fs;                                    // f1 belongs to branch a, f2 to branch b
                 f12[use_b ? 0 : 1] += fo;
             }
