@@ -142,8 +142,11 @@ __device__ inline double range_sum(const Prefix& p, long long s, long long e1) {
 // ---------------------------------------------------------------- block value / sign
 template <int LOSS>
 __device__ inline double block_value(double ssig, double sm, double cnt, double rho) {
-    // src/util/pav.py:134-140: solve with (sum sigma / len, sum m / len)
-    return rbl::prox<LOSS>(ssig / cnt, rho, sm / cnt);
+    // src/util/pav.py:134-140: solve with (sum sigma / len, sum m / len).  The safeguarded Newton starts from the
+    // expansion around the mean of m (device_math.h: prox_bce_est - 2-3 exponentials per block) instead of cold from
+    // x = m (6-8, with IEEE divisions, until the iterate repeats): same root to rounding.  With rank weights that pool
+    // everywhere (EHRM's CPT weights) these solves, not level 0, are what k_pav_bottom / k_pav_upper spend their time on.
+    return rbl::prox_est<LOSS>(ssig / cnt, rho, sm / cnt);
 }
 
 // ---------------------------------------------------------------- one seam merge
