@@ -666,6 +666,8 @@ def test_single_sweep_paths(loss, reg_kind):
     (300, 2048, "f32", "hinge", "l1_reg"),                   # the widest row of the wave-per-row kernel (fp32: 8 packets per lane)
     (7, 9000, "f32", "binary_cross_entropy", "l1_reg"),      # 5 packets per thread (C5's kernel): fewer rows than one sub-batch row set
     (49, 10000, "f32", "hinge", "l2_reg"),                   # C5's width: one super-batch of 48 rows + 1 row
+    (130, 11000, "f32", "binary_cross_entropy", "l2_reg"),   # 6 packets per thread, two rows per sub-batch (round 3)
+    (70, 15000, "f32", "hinge", "l1_reg"),                   # 8 packets per thread: the widest shape (w = 117 KB of LDS)
 ])
 def test_single_sweep_wide_rows(rows, cols, storage, loss, reg_kind):
     """The single-sweep path for every row width (sweep_erm.hip: wave-per-row up to 4 / 8 passes,
