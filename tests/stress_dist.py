@@ -3,7 +3,9 @@ collected by pytest): random family / shape / number of ranks (2..8, ranks as th
 process with hub collectives, tests/test_gpu_dist.py) against the single-handle run.
     python tests/stress_dist.py SEED TRIALS
 Round 1: 220 trials (seeds 1-4), worst relative deviation 2e-12, ranks bit-identical in all.  Round 2 (seed 7, 60
-trials; the 28 superquantile / aorr draws of 4096 rows or more take the sort-free distributed z-step rbl_zbd_*): clean."""
+trials; the 28 superquantile / aorr draws of 4096 rows or more take the sort-free distributed z-step rbl_zbd_*): clean.
+Round 3 (seeds 9 and 11, 40 + 150 trials, 2-8 ranks; early-out of the root passes, staged collectives under gloo): worst
+relative deviation of w 3e-12, ranks bit-identical in all."""
 import os
 import sys
 import threading
