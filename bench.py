@@ -69,6 +69,28 @@ CONFIGS = {
 }
 
 
+def device_copy_rate(torch, device, gib=8, repeats=3):
+    """Measured device-to-device copy rate of this box ("also report against the measured device-copy
+    bandwidth of the box"): a `gib` GiB buffer copied `repeats` times on torch's current stream, best repeat, bytes read +
+    bytes written per second.  Runs during set-up (before the Gram product); ~20 ms."""
+    n = (gib << 30) // 4
+    src = torch.empty(n, dtype=torch.float32, device=device).fill_(1.0)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    best = None
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None or ms < best else best
+    del src, dst
+    torch.cuda.empty_cache()
+    return 2.0 * n * 4 / (best * 1e-3) / 1e9
+
+
 def _host_threads():
     try:
         from threadpoolctl import threadpool_info
@@ -347,6 +369,7 @@ def main():
         gc.collect()
         gc.disable()      # no collector pause inside the timed region (with N ranks the slowest one sets the pace)
 
+    copy_gbs = device_copy_rate(torch, torch.device("cuda", local_rank)) if world == 1 else None
     if sharded:
         drv = ShardedADMM(GpuEngine(s, local_rank))
         drv.always_allreduce = a.sharded_driver
@@ -457,6 +480,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_" + dom,
+                         "device_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
+                         "achieved_over_device_copy": round(achieved / copy_gbs, 3) if copy_gbs else None,
                          "bytes_per_launch": bytes_per_launch, "timed_every": prof_every,
                          "kernel_ms_first": round(smp[0], 4) if smp else None,
                          "kernel_ms_last": round(smp[-1], 4) if smp else None,
