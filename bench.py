@@ -72,7 +72,7 @@ CONFIGS = {
 def device_copy_rate(torch, device, gib=8, repeats=3):
     """Measured device-to-device copy rate of this box ("also report against the measured device-copy
     bandwidth of the box"): a `gib` GiB buffer copied `repeats` times on torch's current stream, best repeat, bytes read +
-    bytes written per second.  Runs during set-up (before the Gram product); ~20 ms."""
+    bytes written per second.  Runs after the timed region; ~20 ms."""
     n = (gib << 30) // 4
     src = torch.empty(n, dtype=torch.float32, device=device).fill_(1.0)
     dst = torch.empty_like(src)
@@ -369,7 +369,6 @@ def main():
         gc.collect()
         gc.disable()      # no collector pause inside the timed region (with N ranks the slowest one sets the pace)
 
-    copy_gbs = device_copy_rate(torch, torch.device("cuda", local_rank)) if world == 1 else None
     if sharded:
         drv = ShardedADMM(GpuEngine(s, local_rank))
         drv.always_allreduce = a.sharded_driver
@@ -415,6 +414,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the box's own device-to-device copy rate, AFTER the timed region (measured before it - 16 GB allocated and freed
+    # ahead of the data - the sweep ran 1-1.5 % slower for the whole run: interleaved on one box 277.9 / 278.3 against
+    # 282.0 / 281.6 it/s; physical placement of the 24 GB matrix)
+    copy_gbs = (device_copy_rate(torch, torch.device("cuda", local_rank))
+                if world == 1 and os.environ.get("RBL_BENCH_NO_COPY") != "1" else None)
     esz = 4 if a.storage == "f32" else 8
     kt = {}
     for name, kid in (("gemv", _lib.KERNEL_GEMV), ("gemvt", _lib.KERNEL_GEMVT), ("sweep_erm", _lib.KERNEL_SWEEP_ERM)):
