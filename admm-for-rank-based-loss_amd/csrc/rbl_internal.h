@@ -224,6 +224,7 @@ struct WstepWorkspace {
     int launch_seq; // launches so far (the tags of a launch: launch_seq << 12 | exchange number)
     bool gw_valid;  // ws.Gy holds G w of the w the last run_wstep returned
     int form;       // how the last run_wstep ran (rbl_stats.wstep_form)
+    int ncg_skip, ncg_backoff;   // persistent nonlinear CG: w-steps left without / length of the pause of its linear first phase
 };
 constexpr int WSTEP_BAR_UINTS = 2 * 10 * 32;
 constexpr int WSTEP_PERSIST_MAX_LD = 2048;                                  // 8 vector elements per thread of a 256-thread block

@@ -239,6 +239,7 @@ __global__ __launch_bounds__(UPD_THREADS) void k_cg_update(long long ld, const d
 // Preconditioned nonlinear CG.  grad F = rho (G w - q) + h'(w); preconditioner M = diag(rho G_jj + h''(w_j))^-1.
 struct NcgParams {
     double rho, reg, t, tol;
+    int active;   // persistent kernel: try the linear solve on the incoming Huber pattern first (k_ncg_persist)
 };
 __device__ inline double hub_g(double u, double reg, double t) {   // h_t'(u), w_LBFGS.py:21-28
     return fabs(u) <= t ? reg * u / (2.0 * t) : copysign(0.5 * reg, u);
@@ -527,7 +528,11 @@ bool ncg_persist_try(const double* G, int64_t ld, const double* q, NcgParams P, 
 int run_ncg(const double* G, int64_t ld, const double* q, double rho, double reg, double smooth_t, double L, double tol,
             int max_inner, double* w, WstepWorkspace& ws, int* iters_host, hipStream_t s, bool want_Gw) {
     const unsigned sg = symv_grid(ld);
-    NcgParams P{rho, reg, smooth_t, tol};
+    static const int ncg_active = [] {
+        const char* e = getenv("RBL_NCG_ACTIVE");     // =0: the nonlinear CG alone (comparison)
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    NcgParams P{rho, reg, smooth_t, tol, ncg_active};
     {
         // one persistent launch (k_ncg_persist) where the row width allows it
         int status = 0, it = 0, rc = RBL_OK;
@@ -876,8 +881,151 @@ __global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __rest
     ++xn;
     if (!wp_exchange<PER>(tag_base + xn, ybuf, x0, ld, gwj, abort_word)) ok = 0;
     if (ok) {
-        double acc[1] = {0.0};
         double gmax = 0.0, qmax = 0.0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = wp_idx(k);
+            if (j < ld) {
+                gmax = fmax(gmax, fabs(P.rho * (gwj[k] - qj[k]) + hub_g(wj[k], P.reg, P.t)));
+                qmax = fmax(qmax, P.rho * fabs(qj[k]));
+            } else {
+                gwj[k] = 0.0;
+            }
+        }
+        gmax = block_max1<WP_THREADS>(gmax, red);
+        qmax = block_max1<WP_THREADS>(qmax, red);
+        thr = P.tol * fmax(qmax, 0.5 * P.reg);
+        done = gmax <= thr ? 1 : 0;
+    }
+    // Phase A: the Huber term is quadratic (|w_j| <= t) or linear (|w_j| > t) in every coordinate, so WITH THE PATTERN OF
+    // THE SOLUTION KNOWN the w-step is the linear system (rho G + diag(c)) w = rho q - s, c_j = reg/(2t) on the quadratic
+    // coordinates, s_j = (reg/2) sign(w_j) on the others.  Between two ADMM iterations the pattern rarely changes: take it
+    // from the incoming w and run Jacobi-preconditioned CG on that system (one all-gather per iteration, as below; a linear
+    // CG gains 1-1.5 digits per iteration on this spectrum where the nonlinear one needs restarts).  The result is accepted
+    // only if it lies in the assumed pattern - then the linearised gradient IS the gradient and the stop rule is the
+    // nonlinear CG's, on the true gradient.  With a wrong pattern the system can be singular on the linear coordinates
+    // (collinear columns) and its "solution" 1e14 away, so the attempt is dropped early: when an iterate is still outside
+    // the pattern at the 6th step (the first steps often cross and come back: 6M x 1000, iterations 50-58 of an sADMM
+    // run - 2, 2, 1, 0, 0 coordinates outside, converged in 5-7 steps where the nonlinear CG takes 23-33), when the
+    // residual grows 100-fold, or after 25 steps.  The nonlinear CG then starts from the point reached if the true
+    // gradient is smaller there than at the incoming w (a wrong-pattern solution is often 1e-6 from the right one),
+    // else from the incoming w as if nothing had happened.  The host stops trying for a while after a dropped attempt
+    // (run_ncg_persist).
+    int phase_a = -1;   // -1 not attempted, 0 attempted and dropped, 1 accepted
+    if (ok && !done && P.active) {
+        phase_a = 0;
+        double cj[PER], rj[PER], zj[PER], sgj[PER], w0j[PER], gw0j[PER];
+        double a1[1] = {0.0};
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = wp_idx(k);
+            cj[k] = rj[k] = zj[k] = pj[k] = sgj[k] = 0.0;
+            w0j[k] = wj[k];
+            gw0j[k] = gwj[k];
+            if (j < ld) {
+                cj[k] = hub_c(wj[k], P.reg, P.t);
+                sgj[k] = (cj[k] == 0.0) ? copysign(1.0, wj[k]) : 0.0;   // the sign the linear part assumes
+                rj[k] = -(P.rho * (gwj[k] - qj[k]) + hub_g(wj[k], P.reg, P.t));
+                zj[k] = precond_inv(P.rho, gdj[k], cj[k]) * rj[k];
+                pj[k] = zj[k];
+                a1[0] += rj[k] * zj[k];
+            }
+        }
+        rbl::block_sum<1, WP_THREADS>(a1, red);
+        double rz = a1[0];
+        int lin = 0;
+        double rmax0 = 0.0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) rmax0 = fmax(rmax0, fabs(rj[k]));
+        rmax0 = block_max1<WP_THREADS>(rmax0, red);
+        for (int itA = 0; itA < 25 && iters < max_iter; ++itA) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int j = wp_idx(k);
+                if (j < ld) xs[j] = pj[k];
+            }
+            __syncthreads();
+            wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, ybuf);      // G p
+            ++xn;
+            if (!wp_exchange<PER>(tag_base + xn, ybuf, (xn & 1) ? x0 : x1, ld, gpj, abort_word)) {
+                ok = 0;
+                break;
+            }
+            double b1[1] = {0.0};
+#pragma unroll
+            for (int k = 0; k < PER; ++k) b1[0] += pj[k] * (P.rho * gpj[k] + cj[k] * pj[k]);
+            rbl::block_sum<1, WP_THREADS>(b1, red);
+            ++iters;
+            if (!(b1[0] > 0.0)) break;
+            const double alpha = rz / b1[0];
+            double b2[2] = {0.0, 0.0};
+            double rmax = 0.0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int j = wp_idx(k);
+                if (j < ld) {
+                    wj[k] += alpha * pj[k];
+                    gwj[k] += alpha * gpj[k];
+                    rj[k] -= alpha * (P.rho * gpj[k] + cj[k] * pj[k]);
+                    zj[k] = precond_inv(P.rho, gdj[k], cj[k]) * rj[k];
+                    b2[0] += rj[k] * zj[k];
+                    rmax = fmax(rmax, fabs(rj[k]));
+                    const bool quad = fabs(wj[k]) <= P.t;
+                    if (quad != (cj[k] != 0.0) || (!quad && copysign(1.0, wj[k]) != sgj[k])) b2[1] += 1.0;
+                }
+            }
+            rbl::block_sum<2, WP_THREADS>(b2, red);
+            rmax = block_max1<WP_THREADS>(rmax, red);
+            if ((b2[1] != 0.0 && itA >= 5) || rmax > 100.0 * rmax0) break;   // still outside the pattern / diverging
+            if (rmax <= thr) {
+                lin = b2[1] == 0.0 ? 1 : 0;
+                break;
+            }
+            const double beta = (rz > 0.0) ? b2[0] / rz : 0.0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) pj[k] = zj[k] + beta * pj[k];
+            rz = b2[0];
+        }
+        if (ok && lin) {
+            // inside the assumed pattern the linearised gradient IS the gradient; the recurrence's residual is not trusted
+            double gmax = 0.0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int j = wp_idx(k);
+                if (j < ld) gmax = fmax(gmax, fabs(P.rho * (gwj[k] - qj[k]) + hub_g(wj[k], P.reg, P.t)));
+            }
+            gmax = block_max1<WP_THREADS>(gmax, red);
+            if (gmax <= thr) {
+                done = 1;
+                phase_a = 1;
+            }
+        }
+        if (ok && !done) {
+            // not accepted: the nonlinear CG starts from the point reached if the true gradient is smaller there than at
+            // the incoming w (a wrong-pattern solution is often 1e-6 from the right one), else from the incoming w
+            double ga = 0.0, g0 = 0.0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int j = wp_idx(k);
+                if (j < ld) {
+                    ga = fmax(ga, fabs(P.rho * (gwj[k] - qj[k]) + hub_g(wj[k], P.reg, P.t)));
+                    g0 = fmax(g0, fabs(P.rho * (gw0j[k] - qj[k]) + hub_g(w0j[k], P.reg, P.t)));
+                }
+            }
+            ga = block_max1<WP_THREADS>(ga, red);
+            g0 = block_max1<WP_THREADS>(g0, red);
+            if (!(ga < g0)) {
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    wj[k] = w0j[k];
+                    gwj[k] = gw0j[k];
+                }
+            }
+        }
+    }
+    if (ok && !done) {
+        // start of the nonlinear CG at the current point
+        double acc[1] = {0.0};
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int j = wp_idx(k);
@@ -887,18 +1035,10 @@ __global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __rest
                 sj[k] = precond_inv(P.rho, gdj[k], hub_c(wj[k], P.reg, P.t)) * g;
                 pj[k] = -sj[k];
                 acc[0] += g * sj[k];
-                gmax = fmax(gmax, fabs(g));
-                qmax = fmax(qmax, P.rho * fabs(qj[k]));
-            } else {
-                gwj[k] = 0.0;
             }
         }
         rbl::block_sum<1, WP_THREADS>(acc, red);
-        gmax = block_max1<WP_THREADS>(gmax, red);
-        qmax = block_max1<WP_THREADS>(qmax, red);
         gs_old = acc[0];
-        thr = P.tol * fmax(qmax, 0.5 * P.reg);
-        done = gmax <= thr ? 1 : 0;
     }
     while (ok && !done && iters < max_iter) {
 #pragma unroll
@@ -909,7 +1049,7 @@ __global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __rest
         __syncthreads();
         wp_matvec<GLDS>(G, gs, ld, r0, r1, xs, 1.0, 0.0, ybuf);      // G p
         ++xn;
-        if (!wp_exchange<PER>(tag_base + xn, ybuf, (iters & 1) ? x0 : x1, ld, gpj, abort_word)) {
+        if (!wp_exchange<PER>(tag_base + xn, ybuf, (xn & 1) ? x0 : x1, ld, gpj, abort_word)) {
             ok = 0;
             break;
         }
@@ -996,7 +1136,10 @@ __global__ __launch_bounds__(WP_THREADS) void k_ncg_persist(const double* __rest
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) wp_publish(pin, ok ? done : -2, iters);
+        if (threadIdx.x == 0) {
+            pin[2] = phase_a;
+            wp_publish(pin, ok ? done : -2, iters);
+        }
     }
 }
 
@@ -1101,6 +1244,8 @@ int run_ncg_persist(const WpPlan& pl, const double* G, int64_t ld, const double*
                     WstepWorkspace& ws, bool want_Gw, int* status, int* iters, hipStream_t s) {
     int* pin = ws.pin + 8;
     pin[0] = -1;
+    pin[2] = -1;
+    if (ws.ncg_skip > 0) P.active = 0;
     ws.launch_seq = (ws.launch_seq + 1) & 0xfffff;
     if (ws.launch_seq == 0) ws.launch_seq = 1;
     const unsigned tag_base = (unsigned)ws.launch_seq << 12;
@@ -1129,6 +1274,17 @@ int run_ncg_persist(const WpPlan& pl, const double* G, int64_t ld, const double*
     const volatile int* st = pin;
     *status = st[0];
     *iters = st[1];
+    // the linear first phase pays where the Huber pattern is stable between ADMM iterations (6M x 1000: 252 -> 270 it/s)
+    // and costs its iterations where it is not (a few thousand rows: +10-40 % inner iterations if tried every time):
+    // after a dropped attempt the next 1, 2, 4, ... 16 w-steps run the nonlinear CG alone
+    if (st[2] == 1) {
+        ws.ncg_backoff = 0;
+    } else if (st[2] == 0) {
+        ws.ncg_backoff = ws.ncg_backoff ? (ws.ncg_backoff < 16 ? 2 * ws.ncg_backoff : 16) : 1;
+        ws.ncg_skip = ws.ncg_backoff;
+    } else if (ws.ncg_skip > 0) {
+        --ws.ncg_skip;
+    }
     return RBL_OK;
 }
 
