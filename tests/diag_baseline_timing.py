@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Epoch times of the competitor baselines (SGDmethod / LSVRGmethod) on the GPU next to the CPU
-restatement (oracle/baselines.py) on the reference's C1 shape (6000 x 1000):  python tools/baseline_timing.py"""
+restatement (oracle/baselines.py) on the reference's C1 shape (6000 x 1000):  python tests/diag_baseline_timing.py"""
 import os
 import sys
 import time

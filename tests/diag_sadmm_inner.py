@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Inner iterations of the smoothed-l1 w-step over 45 sADMM iterations of a small problem (the oracle's generator), for
 comparing RBL_NCG_ACTIVE=0 (nonlinear CG alone) with the default (linear first phase, csrc/wstep.hip):
-    python tools/sadmm_inner.py ROWS COLS T0"""
+    python tests/diag_sadmm_inner.py ROWS COLS T0"""
 import sys, os
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import admm_for_rank_based_loss_amd as R
 from oracle import problems
