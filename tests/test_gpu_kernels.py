@@ -283,6 +283,40 @@ def test_wstep_vs_oracle_and_golden(L):
     assert np.max(np.abs(w3 - ref3)) <= 1e-10 * max(1.0, np.max(np.abs(ref3)))
 
 
+@pytest.mark.parametrize("d", [700, 1500], ids=["d700_G_rows_in_LDS", "d1500_8_per_thread_G_from_L2"])
+def test_persistent_d_space_wsteps_are_optimal(L, d):
+    """The one-launch forms of the ridge CG and of the smoothed-l1 w-step (csrc/wstep.hip: k_cg_persist, k_ncg_persist with
+    its linear first phase) at widths the iterate tests do not reach, judged by their optimality conditions
+    (w_LBFGS.py:11-62): cold start, warm start from the solution of a slightly different right-hand side (the case the
+    linear phase is made for), a start far from the solution's Huber pattern, and a Gram matrix with two exactly collinear
+    columns (a wrong pattern then makes the linear system singular)."""
+    rng = np.random.default_rng(d)
+    n = 3000
+    D = rng.standard_normal((n, d))
+    D[:, 5] = 2.0 * D[:, 3] - D[:, 4]                       # exactly collinear, as the generator's redundant columns
+    D[:, :8] *= 3.0
+    G = D.T @ D
+    c = rng.standard_normal(n)
+    rho, reg = 1e-3, 0.05
+    hub = lambda w, t: np.where(np.abs(w) <= t, reg * w / (2 * t), 0.5 * reg * np.sign(w))
+    for trial, t in enumerate((1.0, 1e-2, 1e-4)):
+        q = D.T @ (c + 0.1 * trial)
+        w_r, _ = L.k_wstep(2, G, q, rho, reg, np.zeros(d))
+        assert np.max(np.abs(rho * (G @ w_r - q) + reg * w_r)) <= 1e-10 * np.max(np.abs(rho * q)), ("ridge", d, t)
+        scale = max(np.max(np.abs(rho * q)), 0.5 * reg)
+        w_c, it_c = L.k_wstep(3, G, q, rho, reg, np.zeros(d), smooth_t=t)                       # cold
+        assert np.max(np.abs(rho * (G @ w_c - q) + hub(w_c, t))) <= 1e-10 * scale, ("cold", d, t, it_c)
+        q2 = q + 1e-4 * np.max(np.abs(q)) * rng.standard_normal(d)
+        w_w, it_w = L.k_wstep(3, G, q2, rho, reg, w_c, smooth_t=t)                               # warm: pattern (nearly) stable
+        assert np.max(np.abs(rho * (G @ w_w - q2) + hub(w_w, t))) <= 1e-10 * scale, ("warm", d, t, it_w)
+        w_f, it_f = L.k_wstep(3, G, q, rho, reg, 50.0 * rng.standard_normal(d), smooth_t=t)      # far: every sign assumed wrong
+        assert np.max(np.abs(rho * (G @ w_f - q) + hub(w_f, t))) <= 1e-10 * scale, ("far", d, t, it_f)
+        # (with collinear columns the minimiser need not be unique outside the quadratic zone: compare the objective)
+        phi = lambda w: (0.5 * rho * w @ (G @ w) - rho * q @ w
+                         + np.sum(np.where(np.abs(w) <= t, reg * w * w / (4 * t), 0.5 * reg * (np.abs(w) - 0.5 * t))))
+        assert abs(phi(w_f) - phi(w_c)) <= 1e-10 * max(1.0, abs(phi(w_c))), ("same minimum", d, t, phi(w_f), phi(w_c))
+
+
 def test_lasso_active_set_solver(L):
     """The l1 w-step's exact active-set (feature-sign) kernel: cold start, warm start, exactly
     collinear columns, supports beyond its capacity (falls back to FISTA) - always the exact
