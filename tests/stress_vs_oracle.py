@@ -12,7 +12,8 @@ trials with RBL_ZBAND_MIN_N=16 in the environment (the 54 superquantile / aorr d
 objective of csrc/zband.hip): no mismatch.  Round 3, final library (one-block-per-CU sweep shapes, 8-packet fp32 rows,
 persistent w-steps, block values from the expansion around the block mean): seeds 41 (120) and 51 (500 trials): worst
 primal 2.8e-10, worst w 1.8e-11 (75 EHRM and 51 sADMM draws among the 500); seeds 43 (80) and 53 (300) with
-RBL_ZBAND_MIN_N=16: worst 1.9e-11; no mismatch."""
+RBL_ZBAND_MIN_N=16: worst 1.9e-11; after the linear first phase of the smoothed-l1 w-step: seeds 61 (250) and 71 (700 trials, 69 sADMM
+draws, worst of those 1.7e-12); no mismatch."""
 import os
 import sys
 import time
