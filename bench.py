@@ -325,6 +325,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 flow of this script on a ONE-GPU box (tools/rehearse_bench_n2.sh): every rank on device 0,
+    # gloo instead of RCCL (which refuses two ranks on one device; the driver then stages its collectives through the
+    # host).  The line it prints says so and is not a measurement of anything.
+    rehearsal = os.environ.get("RBL_BENCH_REHEARSE_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
@@ -339,7 +345,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29733")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if _lib.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: librbl has no CPU fallback")
 
@@ -467,7 +476,7 @@ def main():
             "metric": "ADMM iterations/sec + wall-clock to 1e-6 primal gap, n×d synthetic",
             "value": a.steps / dt, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" if not rehearsal else "synthetic - REHEARSAL: all ranks on one GPU over gloo, not a measurement",
             "config": {"workload": cfg["label"], "rows": n_total, "cols": d, "storage": a.storage,
                        "sharding": f"rows/{world}", "driver": "ShardedADMM" if sharded else "single handle", "setup_s": round(t_setup, 3),
                        "inner_iters_last": int(last.inner_iters), "phase_ms_last": ({
