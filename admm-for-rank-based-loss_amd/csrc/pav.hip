@@ -552,7 +552,11 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
     __shared__ double spm[PB_TILE + 1];
     __shared__ double wsum[2][PV_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long base = (long long)blockIdx.x * PB_TILE;
+    // Tiles are taken from the HIGH end of the order first: with rank weights that grow towards the top (EHRM's CPT weights,
+    // extremile, esrm) the pooling - chains of dependent block solves - concentrates in the last tiles, and a tile that
+    // starts last is the kernel's tail (EHRM, 6.25M positions: the average wave lives 13 us, the kernel took 296 us).
+    const long long tile = (long long)gridDim.x - 1 - blockIdx.x;
+    const long long base = tile * PB_TILE;
     const bool use_b = SPEC ? (spec != 0) : (branch && *branch);
     const double* sg = use_b ? sb : sa;
     const double* u0 = (!SPEC && u0a) ? (use_b ? u0b : u0a) : nullptr;
@@ -636,8 +640,8 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
         // this tile's share of the two singleton-stage sums (fixed order: deterministic)
         rbl::block_sum<2, PV_THREADS>(f12, &wsum[0][0]);
         if (tid == 0) {
-            fpart[2 * (long long)blockIdx.x + 0] = f12[0];
-            fpart[2 * (long long)blockIdx.x + 1] = f12[1];
+            fpart[2 * tile + 0] = f12[0];
+            fpart[2 * tile + 1] = f12[1];
         }
         __syncthreads();
     }
