@@ -534,6 +534,15 @@ constexpr int PB_TILE = 1 << PB_TILE_LOG;  // 2048 positions, 48 KB of LDS
 constexpr int PB_PER = PB_TILE / PV_THREADS;
 static_assert(PB_PER == 8, "the sequential step keeps its block starts in the low 8 bits of a mask");
 
+// tools/pav_lab.hip builds this file with PAV_LAB defined: block 0's wall-clock stamps at the stages of k_pav_bottom
+#ifdef PAV_LAB
+#define PAV_LAB_STAMP(i)                                                             \
+    do {                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x < 8) pav_lab_stamps[blockIdx.x * 32 + (i)] = (long long)wall_clock64(); \
+    } while (0)
+#else
+#define PAV_LAB_STAMP(i) do { } while (0)
+#endif
 template <int LOSS, bool SPEC>
 __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restrict__ ms, const double* __restrict__ sa,
                                                             const double* __restrict__ sb, const int* __restrict__ branch,
@@ -545,6 +554,7 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
     // reads and writes only its own tile).  skip_if_branch >= 0: nothing to do when *branch says so (see above).
     // SPEC: sa / sb / B / spec as described above, fpart[2 * block + {0, 1}] receive this tile's share of f1 / f2.
     if (!SPEC && skip_if_branch >= 0 && branch && *branch == skip_if_branch) return;
+    PAV_LAB_STAMP(0);
     const int wave_top = bflags & 1;
     const bool seq_levels = !(bflags & 2);
     __shared__ double su[PB_TILE];
@@ -646,6 +656,7 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
         __syncthreads();
     }
 
+    PAV_LAB_STAMP(1);
     const LdsAcc ac{su, spa, spm};
     u32 merges = 0;
     // Levels 1-3: sequential PAV over the thread's own PB_PER positions (see the header comment).  `starts`: bit j set
@@ -683,6 +694,7 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
         }
         __syncthreads();
     }
+    PAV_LAB_STAMP(2);
     // Levels with short segments: the thread that merged a seam writes the pooled range itself.
     // From PB_COOP on (at most PB_TILE / (2 PB_COOP) seams per level) the pooled ranges get long
     // (up to the whole tile) and a single thread writing them would serialise the level: the
@@ -746,8 +758,10 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
             }
             __syncthreads();
         }
+        PAV_LAB_STAMP(3 + (31 - __clz(half)));      // after the level that joins segments of `half` positions
     }
     for (int i = tid; i < nt; i += PV_THREADS) u_out[base + i] = su[i];
+    PAV_LAB_STAMP(20);
     if (merges) atomicAdd(merge_counter, merges);
 }
 

@@ -26,6 +26,15 @@ rho = st.rho_next
 sa, sb = s.sigma()
 s.close()
 print("rho", rho, "branch", st.ehrm_branch, "m range", m[0], m[-1], flush=True)
+if "--dump" in sys.argv:      # input of tools/pav_lab.hip: the 16 highest tiles and 16 from the middle (branch b weights)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    for tag, lo, hi in (("top", n - 16 * 2048, n), ("mid", n // 2, n // 2 + 16 * 2048)):
+        m[lo:hi].tofile(os.path.join(out, "pav_lab_ms_%s.bin" % tag))
+        sa[lo:hi].tofile(os.path.join(out, "pav_lab_sa_%s.bin" % tag))
+        sb[lo:hi].tofile(os.path.join(out, "pav_lab_sb_%s.bin" % tag))
+    print("dumped; rho =", repr(rho), flush=True)
+    sys.exit(0)
 T = 2048
 for name, lo, hi in (("all", 0, n), ("first half", 0, n // 2), ("second half", n // 2, n), ("last 10%", n - n // 10, n),
                      ("last 1%", n - n // 100, n), ("last 16 tiles", n - 16 * T, n), ("last tile", n - T, n),
