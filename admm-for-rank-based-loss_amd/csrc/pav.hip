@@ -573,25 +573,28 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
     long long nt = n - base;  // valid positions of this tile
     if (nt > PB_TILE) nt = PB_TILE;
 
-    // level 0 + thread-local sums (PB_PER consecutive positions per thread)
-    double ls[PB_PER], lm[PB_PER];
+    // level 0 + thread-local sums (PB_PER consecutive positions per thread).  ONE copy of the element code (the loop is not
+    // unrolled: eight inlined copies of the two safeguarded Newton solves made the speculating kernel 19 000 instructions
+    // long); the position's sigma and m are parked in the prefix arrays until the prefixes replace them below.
     double ts = 0.0, tm = 0.0;
     double f12[2] = {0.0, 0.0};
     const double sigB = SPEC ? rbl::sigmoid1(B) : 0.0, spB = SPEC ? rbl::softplus(B) : 0.0;
-#pragma unroll
+#pragma clang loop unroll(disable)
     for (int k = 0; k < PB_PER; ++k) {
         const int i = tid * PB_PER + k;
         const bool ok = i < nt;
-        ls[k] = ok ? sg[base + i] : 0.0;
-        lm[k] = ok ? ms[base + i] : 0.0;
+        const double ls_k = ok ? sg[base + i] : 0.0;
+        const double lm_k = ok ? ms[base + i] : 0.0;
+        spa[i] = ls_k;
+        spm[i] = lm_k;
         if (SPEC) {
             double x = 0.0;
             if (ok) {
                 // one exponential serves sigmoid(m) and softplus(m); the two objective values are expanded around m
                 // (device_math.h: softplus_near), the two prox problems start from the O(a^4) estimate
-                const double m = lm[k], em = exp(-fabs(m)), inv = 1.0 / (1.0 + em);
+                const double m = lm_k, em = exp(-fabs(m)), inv = 1.0 / (1.0 + em);
                 const double sm = (m > 0.0) ? inv : em * inv, spm = fmax(m, 0.0) + log1p(em);
-                x = rbl::prox_bce_est(ls[k], rho, m, sm);                    // level 0 of the speculated branch
+                x = rbl::prox_bce_est(ls_k, rho, m, sm);                    // level 0 of the speculated branch
                 const double so = (use_b ? sa : sb)[base + i];               // the weight of the other branch
                 // speculated branch: clipped at B from its own side; other branch: B itself wherever its prox lies beyond B
                 double os = x, oo;
@@ -602,17 +605,17 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
                     if (os > B) os = B;
                     oo = (m <= B + so * sigB / rho) ? B : fmax(rbl::prox_bce_est(so, rho, m, sm), B);
                 }
-                const double fs = ls[k] * (os == B ? spB : rbl::softplus_near(os, m, spm, sm)) + 0.5 * rho * (os - m) * (os - m);
+                const double fs = ls_k * (os == B ? spB : rbl::softplus_near(os, m, spm, sm)) + 0.5 * rho * (os - m) * (os - m);
                 const double fo = so * (oo == B ? spB : rbl::softplus_near(oo, m, spm, sm)) + 0.5 * rho * (oo - m) * (oo - m);
                 f12[use_b ? 1 : 0] += fs;                                    // f1 belongs to branch a, f2 to branch b
                 f12[use_b ? 0 : 1] += fo;
             }
             su[i] = x;
         } else {
-            su[i] = ok ? (u0 ? u0[base + i] : rbl::prox_est<LOSS>(ls[k], rho, lm[k])) : 0.0;
+            su[i] = ok ? (u0 ? u0[base + i] : rbl::prox_est<LOSS>(ls_k, rho, lm_k)) : 0.0;
         }
-        ts += ls[k];
-        tm += lm[k];
+        ts += ls_k;
+        tm += lm_k;
     }
     double is = ts, im = tm;
 #pragma unroll
@@ -636,10 +639,11 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
 #pragma unroll
     for (int k = 0; k < PB_PER; ++k) {
         const int i = tid * PB_PER + k;
+        const double ls_k = spa[i], lm_k = spm[i];   // parked by this thread above
         spa[i] = ps;
         spm[i] = pm_;
-        ps += ls[k];
-        pm_ += lm[k];
+        ps += ls_k;
+        pm_ += lm_k;
     }
     if (tid == PV_THREADS - 1) {
         spa[PB_TILE] = ps;
