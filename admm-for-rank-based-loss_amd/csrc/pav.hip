@@ -607,8 +607,8 @@ __global__ __launch_bounds__(PV_THREADS) void k_pav_bottom(const double* __restr
                 }
                 const double fs = ls_k * (os == B ? spB : rbl::softplus_near(os, m, spm, sm)) + 0.5 * rho * (os - m) * (os - m);
                 const double fo = so * (oo == B ? spB : rbl::softplus_near(oo, m, spm, sm)) + 0.5 * rho * (oo - m) * (oo - m);
-                f12[use_b ? 1 : 0] += fs;                                    // f1 belongs to branch a, f2 to branch b
-                f12[use_b ? 0 : 1] += fo;
+                f12[0] += use_b ? fo : fs;                                   // f1 belongs to branch a, f2 to branch b
+                f12[1] += use_b ? fs : fo;
             }
             su[i] = x;
         } else {
