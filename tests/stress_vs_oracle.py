@@ -13,7 +13,12 @@ objective of csrc/zband.hip): no mismatch.  Round 3, final library (one-block-pe
 persistent w-steps, block values from the expansion around the block mean): seeds 41 (120) and 51 (500 trials): worst
 primal 2.8e-10, worst w 1.8e-11 (75 EHRM and 51 sADMM draws among the 500); seeds 43 (80) and 53 (300) with
 RBL_ZBAND_MIN_N=16: worst 1.9e-11; after the linear first phase of the smoothed-l1 w-step: seeds 61 (250) and 71 (700 trials, 69 sADMM
-draws, worst of those 1.7e-12); no mismatch."""
+draws, worst of those 1.7e-12); no mismatch.  Seed 81 (600 trials, final library): 2 flagged, both aorr / hinge / sADMM draws whose
+first w-step returns w ~ 1e-9 (dual residual 1.1e-9) and whose final w is exactly 0 on both sides: m = D w - lambda/rho is then
+a handful of tied values split only by D w ~ 1e-9 - below what either w-step resolves (gradient tolerance 1e-13 absolute) -
+so the ORDER across aorr's band edges differs between the two solvers from iteration 1 on and the non-convex trajectory
+with it (primal residuals 2e-4 apart, same final w).  Present before and after every change of round 3 (checked against the
+library of commit 6ef7370), with either w-step form.  STRESS_VERBOSE=1 prints the trajectories of a flagged trial."""
 import os
 import sys
 import time
@@ -59,9 +64,11 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
         s = (R.smoothADMMmethod(X, y, max_iter=nit, tol=0.0, storage=storage, t=t_init, **kw) if smooth
              else R.ADMMmethod(X, y, max_iter=nit, tol=0.0, storage=storage, **kw))
         worst = 0.0
+        trace = []
         for i in range(nit):
             st = s._s.step(want_objective=True)
             worst = max(worst, abs(st.primal - ref.primal[i]) / max(1.0, ref.primal[i]))
+            trace.append((i, st.primal, ref.primal[i], st.dual, ref.dual[i], st.objective, ref.objective[i + 1], st.zband, st.inner_iters))
         if smooth:
             s._s.finalize_smooth()
         w = s._s.get_state()["w"]
@@ -72,6 +79,10 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
             tol = 5e-2 if fam in ("aorr", "aorr_dc") else (5e-3 if fam == "ehrm" else 2e-4)
         flag = "" if (worst <= tol and werr <= tol) else "  <<<<<< MISMATCH"
         if flag: bad += 1
+        if flag and os.environ.get("STRESS_VERBOSE") == "1":
+            for row in trace:
+                print("      it %2d primal %.12e / %.12e  dual %.6e / %.6e  obj %.12e / %.12e  zband %d inner %d" % row, flush=True)
+            print("      t_init", t_init, "w (gpu) max", float(np.max(np.abs(w))), "w (oracle) max", float(np.max(np.abs(ref.w))), flush=True)
         print(f"{trial:3d} {fam:13s}{'*' if smooth else ' '}{loss[:5]} {storage} n={n:5d} d={d:4d} {regk}={kw[regk]:.1e} primal_err={worst:.1e} w_err={werr:.1e}{flag}", flush=True)
     except Exception as e:
         print(trial, fam, loss, n, d, "EXC", repr(e)[:200], flush=True); bad += 1
