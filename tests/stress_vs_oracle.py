@@ -17,8 +17,8 @@ draws, worst of those 1.7e-12); no mismatch.  Seed 81 (600 trials, final library
 first w-step returns w ~ 1e-9 (dual residual 1.1e-9) and whose final w is exactly 0 on both sides: m = D w - lambda/rho is then
 a handful of tied values split only by D w ~ 1e-9 - below what either w-step resolves (gradient tolerance 1e-13 absolute) -
 so the ORDER across aorr's band edges differs between the two solvers from iteration 1 on and the non-convex trajectory
-with it (primal residuals 2e-4 apart, same final w).  Present before and after every change of round 3 (checked against the
-library of commit 6ef7370), with either w-step form.  STRESS_VERBOSE=1 prints the trajectories of a flagged trial."""
+with it (primal residuals 2e-4 apart, same final w).  The same two trials are flagged with round 2's final library (commit
+ce57536) and with either w-step form: not something round 3 changed.  STRESS_VERBOSE=1 prints the trajectories of a flagged trial."""
 import os
 import sys
 import time
